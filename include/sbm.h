@@ -1,0 +1,137 @@
+/*
+ * sbm.h -- C-ABI of the MI355X stereo block-matching disparity engine (libsbm_hip.so).
+ *
+ * This is the drop-in boundary for the dense-disparity provider of sdoira/U96-SLAM:
+ *
+ *   reference call site               src/slam/src/core/main.cpp:197-217
+ *       cv::Ptr<cv::StereoBM> bm = cv::StereoBM::create(16, 9);     (main.cpp:201)
+ *       bm->setROI1 ... bm->setDisp12MaxDiff(1);                    (main.cpp:202-212)
+ *       bm->compute(left, right, disp);                             (main.cpp:215)
+ *   alternative provider, same output  src/slam/src/core/FPGA.cpp:270-279 (receiveDepthMap)
+ *   consumers of the output contract   src/slam/src/core/Stereo.cpp:79-83, SensorData.cpp:50-58,
+ *                                      main.cpp:529-530
+ *
+ * Output contract (identical to cv::StereoBM with a CV_16SC1 destination): int16, value =
+ * 16 * disparity (4 fractional bits); every rejected / uncomputable pixel holds
+ * (minDisparity - 1) * 16.
+ *
+ * All entry points are plain C: pointers, sizes, int status codes. No exceptions, no aborts,
+ * no spinning (contrast the reference's Logger.cpp:52-55). The C++ adaptor that restores the
+ * cv::StereoBM spelling (create / 11 setters / compute) is include/sbm_stereobm.hpp.
+ *
+ * There is NO CPU backend behind this ABI: if no HIP device is usable sbm_create() fails with
+ * SBM_ERR_NO_DEVICE. The CPU restatement used by the tests lives in oracle/ and is never linked here.
+ */
+#ifndef SBM_H_
+#define SBM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBM_VERSION_MAJOR 0
+#define SBM_VERSION_MINOR 1
+
+/* status codes (0 = ok). The negative "parameter" codes map 1:1 onto the CV_Error() checks at the
+ * top of cv::StereoBM::compute (OpenCV calib3d, stereobm.cpp). */
+enum {
+  SBM_OK = 0,
+  SBM_ERR_NULL = -1,             /* null handle / pointer argument                                   */
+  SBM_ERR_SIZE = -2,             /* width/height <= 0, stride < width, left/right size mismatch       */
+  SBM_ERR_PREFILTER_TYPE = -3,   /* preFilterType not XSOBEL (NORMALIZED_RESPONSE: not built yet)     */
+  SBM_ERR_PREFILTER_SIZE = -4,   /* preFilterSize must be odd and within 5..255                       */
+  SBM_ERR_PREFILTER_CAP = -5,    /* preFilterCap must be within 1..63                                 */
+  SBM_ERR_BLOCK_SIZE = -6,       /* blockSize must be odd, within 5..255 and < min(width,height)      */
+  SBM_ERR_NUM_DISPARITIES = -7,  /* numDisparities must be > 0 and divisible by 16                    */
+  SBM_ERR_TEXTURE = -8,          /* textureThreshold must be >= 0                                     */
+  SBM_ERR_UNIQUENESS = -9,       /* uniquenessRatio must be >= 0                                      */
+  SBM_ERR_NO_DEVICE = -20,       /* no usable HIP device / device index out of range                  */
+  SBM_ERR_HIP = -21,             /* a HIP runtime call failed (see sbm_last_hip_error)                */
+  SBM_ERR_NOMEM = -22,           /* device or host allocation failed                                  */
+  SBM_ERR_UNSUPPORTED = -23,     /* valid OpenCV parameters this build cannot run (documented limits) */
+  SBM_ERR_BATCH = -24            /* batch count <= 0                                                  */
+};
+
+#define SBM_PREFILTER_NORMALIZED_RESPONSE 0
+#define SBM_PREFILTER_XSOBEL 1
+
+/* Parameter block: one field per cv::StereoBM setter used at main.cpp:202-212 plus the ones left at
+ * their OpenCV defaults there (preFilterType, preFilterSize). roi = {x, y, width, height}; a roi with
+ * width <= 0 or height <= 0 is "empty" (cv::Rect()) and means "whole image", as at main.cpp:200-203. */
+typedef struct sbm_params {
+  int32_t prefilter_type;      /* setPreFilterType      default SBM_PREFILTER_XSOBEL                  */
+  int32_t prefilter_size;      /* setPreFilterSize      default 9 (unused by XSOBEL)                  */
+  int32_t prefilter_cap;       /* setPreFilterCap       default 31                                    */
+  int32_t block_size;          /* setBlockSize          default 21  (SADWindowSize)                   */
+  int32_t min_disparity;       /* setMinDisparity       default 0                                     */
+  int32_t num_disparities;     /* setNumDisparities     default 64                                    */
+  int32_t texture_threshold;   /* setTextureThreshold   default 10                                    */
+  int32_t uniqueness_ratio;    /* setUniquenessRatio    default 15                                    */
+  int32_t speckle_window_size; /* setSpeckleWindowSize  default 0 (off)                               */
+  int32_t speckle_range;       /* setSpeckleRange       default 0                                     */
+  int32_t disp12_max_diff;     /* setDisp12MaxDiff      default -1 (off)                              */
+  int32_t roi1[4];             /* setROI1                                                             */
+  int32_t roi2[4];             /* setROI2                                                             */
+} sbm_params;
+
+typedef struct sbm_handle sbm_handle; /* opaque; owns a HIP stream and lazily sized device scratch */
+
+/* Fill *p with cv::StereoBM::create(numDisparities, blockSize) defaults (0 -> 64 resp. 21). */
+void sbm_params_default(sbm_params* p, int num_disparities, int block_size);
+
+/* Check p against an image size exactly as cv::StereoBM::compute does before doing any work. */
+int sbm_params_validate(const sbm_params* p, int width, int height);
+
+/* Create an engine on HIP device `device` (>= 0). Parameters are copied. */
+int sbm_create(sbm_handle** out, const sbm_params* p, int device);
+void sbm_destroy(sbm_handle* h);
+
+/* Replace the parameter block (the cv::StereoBM setters). Cheap; scratch is re-sized lazily. */
+int sbm_set_params(sbm_handle* h, const sbm_params* p);
+int sbm_get_params(const sbm_handle* h, sbm_params* p);
+
+/* cv::StereoBM::compute() for one pair in HOST memory (the main.cpp:215 shape): strided, row-major
+ * 8-bit inputs (cv::Mat::data / cv::Mat::step), strided int16 output. Strides are in BYTES.
+ * Synchronous: on return `disp` is filled. */
+int sbm_compute(sbm_handle* h, const uint8_t* left, size_t left_stride, const uint8_t* right, size_t right_stride,
+                int width, int height, int16_t* disp, size_t disp_stride);
+
+/* Same for n independent pairs in host memory (array-of-pointers, common size and strides). */
+int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t left_stride,
+                      const uint8_t* const* right, size_t right_stride, int width, int height,
+                      int16_t* const* disp, size_t disp_stride);
+
+/* n pairs already resident in DEVICE memory, densely packed: left/right = n*height*width bytes,
+ * disp = n*height*width int16. Asynchronous on the handle's stream unless `sync` is non-zero.
+ * This is the entry point bench.py times (inputs resident in HBM when the timed region starts). */
+int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, int width, int height,
+                       void* d_disp, int sync);
+
+/* Block until everything queued on the handle's stream has finished. */
+int sbm_synchronize(sbm_handle* h);
+
+/* Intermediate planes of the LAST sbm_compute_device call, for stage-by-stage parity tests.
+ * which: 0 = prefiltered left (u8), 1 = prefiltered right (u8), 2 = WTA cost plane (int16, valid only
+ * where the pre-LR disparity is valid and disp12_max_diff >= 0), 3 = disparity before LR/speckle (int16).
+ * Copies n*height*width elements into host memory `dst`. */
+int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
+
+/* Per-kernel device time (ms, HIP events on the handle's stream) of the last sbm_compute_device call
+ * made with profiling enabled. names: "prefilter","sad","border","lrcheck","speckle","total". */
+int sbm_set_profiling(sbm_handle* h, int enabled);
+int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
+
+/* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours. */
+void* sbm_stream(sbm_handle* h);
+
+const char* sbm_strerror(int code);
+int sbm_last_hip_error(const sbm_handle* h); /* hipError_t of the last failing runtime call, else 0 */
+int sbm_version(void);                        /* major * 1000 + minor */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBM_H_ */

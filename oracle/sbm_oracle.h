@@ -1,0 +1,87 @@
+/*
+ * sbm_oracle.h -- CPU restatement of the stereo block-matching path. TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into this library.
+ * It is never linked into libsbm_hip.so and the product path never falls back to it.
+ *
+ * What it restates
+ *   The reference obtains its dense disparity from cv::StereoBM (src/slam/src/core/main.cpp:197-217).
+ *   That algorithm lives in OpenCV calib3d (modules/calib3d/src/stereobm.cpp, plus validateDisparity /
+ *   filterSpeckles / getValidDisparityROI in stereosgbm.cpp), a third-party dependency that is NOT
+ *   vendored under /root/reference and whose version the reference does not pin (API usage implies
+ *   OpenCV >= 3.0; restated here from the 4.x sources). Each function below names the OpenCV routine
+ *   it follows.
+ *
+ * Pinning status
+ *   * Prefilter: PINNED by the reference's own golden vectors. data/ref_xsbl_{l,r} is the RTL x-Sobel
+ *     (src/dvp/rtl/xsbl2.v:183-198,661-874) of data/ref_rect_{l,r}; sbmo_prefilter_xsobel_fpga()
+ *     reproduces it exactly and the OpenCV-flavour prefilter satisfies
+ *     cv[y][x] == max(fpga[y][x]-1, 0) on the interior (tests/test_oracle_golden.py).
+ *   * Block-matching output (SAD/WTA/uniqueness/LR/speckle): PARITY UNPINNED -- the reference holds no
+ *     golden disparity map and OpenCV cannot be built or imported in this environment. The restatement
+ *     is cross-checked only against an independent brute-force evaluation of the same definitions.
+ */
+#ifndef SBM_ORACLE_H_
+#define SBM_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/sbm.h" /* sbm_params + status codes (shared vocabulary, no code) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* OpenCV prefilterXSobel (stereobm.cpp). src/dst strides in bytes. */
+void sbmo_prefilter_xsobel(const uint8_t* src, size_t sstride, uint8_t* dst, size_t dstride, int width, int height,
+                           int cap);
+
+/* FPGA flavour: src/dvp/rtl/xsbl2.v (limit() 185-198, horizontal diff 684-698, line buffers 787-857,
+ * edge substitution 869-872, row index hcnt-1 1020-1025). Rows 0 and H-1 are left at `fill` (the
+ * testbench zero-fills them, src/dvp/sim/sim_dvp.v:524-542). */
+void sbmo_prefilter_xsobel_fpga(const uint8_t* src, size_t sstride, uint8_t* dst, size_t dstride, int width,
+                                int height, uint8_t fill);
+
+/* OpenCV getValidDisparityROI (stereosgbm.cpp). roi = {x,y,w,h}; out all-zero when empty. */
+void sbmo_valid_roi(const int32_t roi1[4], const int32_t roi2[4], int min_disparity, int num_disparities,
+                    int block_size, int32_t out[4]);
+
+/* OpenCV findStereoCorrespondenceBM for the row range [row0,row1) of prefiltered images (full-height
+ * pointers; the function itself offsets to row0 exactly like FindStereoCorrespInvoker's rowRange()).
+ * disp: int16 plane (stride in elements), cost: int32 plane or NULL (stride in elements).
+ * Writes columns [0,width) of rows [row0,row1). */
+void sbmo_find_correspondence(const uint8_t* left, const uint8_t* right, size_t stride, int width, int height,
+                              int row0, int row1, const sbm_params* p, int16_t* disp, size_t dstride, int32_t* cost,
+                              size_t cstride);
+
+/* Independent brute-force evaluation of the same per-pixel definition, O(w^2)
+ * per pixel-disparity. Used only to cross-check sbmo_find_correspondence on small images. */
+void sbmo_find_correspondence_bruteforce(const uint8_t* left, const uint8_t* right, size_t stride, int width,
+                                         int height, int row0, int row1, const sbm_params* p, int16_t* disp,
+                                         size_t dstride, int32_t* cost, size_t cstride);
+
+/* OpenCV validateDisparity (stereosgbm.cpp) on `rows` rows. */
+void sbmo_validate_disparity(int16_t* disp, size_t dstride, const int32_t* cost, size_t cstride, int width, int rows,
+                             int min_disparity, int num_disparities, int disp12_max_diff);
+
+/* OpenCV filterSpeckles (stereosgbm.cpp, filterSpecklesImpl<short>). */
+void sbmo_filter_speckles(int16_t* img, size_t stride, int width, int height, int new_val, int max_speckle_size,
+                          int max_diff);
+
+/* cv::StereoBM::compute() end to end. Returns an SBM_* status. If pre_lr / cost_out / pf_l / pf_r are non-NULL
+ * (dense width*height planes) the intermediate stages are copied out for stage-wise parity tests. */
+int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const uint8_t* right, size_t rstride,
+                 int width, int height, int16_t* disp, size_t dstride_bytes, uint8_t* pf_l, uint8_t* pf_r,
+                 int16_t* pre_lr, int32_t* cost_out);
+
+/* n dense pairs, OpenMP across pairs with `threads` threads (cpu_baseline leg of bench.py). Returns status. */
+int sbmo_compute_batch(const sbm_params* p, int n, const uint8_t* left, const uint8_t* right, int width, int height,
+                       int16_t* disp, int threads);
+
+int sbmo_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,200 @@
+"""ctypes binding of the CPU oracle (oracle/libsbm_oracle.so). TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (u96-slam_amd/) never does. See oracle/sbm_oracle.h for what is restated and its pinning status
+(prefilter pinned by the reference's data/ref_xsbl_* vectors; block-matching output: parity unpinned).
+"""
+import ctypes
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_LIB = None
+
+
+class SbmParams(ctypes.Structure):
+    """Mirror of `sbm_params` (include/sbm.h)."""
+
+    _fields_ = [
+        ("prefilter_type", ctypes.c_int32),
+        ("prefilter_size", ctypes.c_int32),
+        ("prefilter_cap", ctypes.c_int32),
+        ("block_size", ctypes.c_int32),
+        ("min_disparity", ctypes.c_int32),
+        ("num_disparities", ctypes.c_int32),
+        ("texture_threshold", ctypes.c_int32),
+        ("uniqueness_ratio", ctypes.c_int32),
+        ("speckle_window_size", ctypes.c_int32),
+        ("speckle_range", ctypes.c_int32),
+        ("disp12_max_diff", ctypes.c_int32),
+        ("roi1", ctypes.c_int32 * 4),
+        ("roi2", ctypes.c_int32 * 4),
+    ]
+
+
+def make_params(num_disparities=64, block_size=21, prefilter_cap=31, min_disparity=0, texture_threshold=10,
+                uniqueness_ratio=15, speckle_window_size=0, speckle_range=0, disp12_max_diff=-1,
+                prefilter_type=1, prefilter_size=9, roi1=(0, 0, 0, 0), roi2=(0, 0, 0, 0)):
+    p = SbmParams()
+    p.prefilter_type, p.prefilter_size, p.prefilter_cap = prefilter_type, prefilter_size, prefilter_cap
+    p.block_size, p.min_disparity, p.num_disparities = block_size, min_disparity, num_disparities
+    p.texture_threshold, p.uniqueness_ratio = texture_threshold, uniqueness_ratio
+    p.speckle_window_size, p.speckle_range, p.disp12_max_diff = speckle_window_size, speckle_range, disp12_max_diff
+    p.roi1[:] = list(roi1)
+    p.roi2[:] = list(roi2)
+    return p
+
+
+def build(force=False):
+    so = _HERE / "libsbm_oracle.so"
+    src = _HERE / "sbm_oracle.c"
+    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "libsbm_oracle.so"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        try:
+            L = ctypes.CDLL(str(so))
+        except OSError:
+            so = build(force=True)
+            L = ctypes.CDLL(str(so))
+        u8p, i16p, i32p = (ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int32))
+        sz, ci = ctypes.c_size_t, ctypes.c_int
+        pp = ctypes.POINTER(SbmParams)
+        L.sbmo_prefilter_xsobel.argtypes = [u8p, sz, u8p, sz, ci, ci, ci]
+        L.sbmo_prefilter_xsobel.restype = None
+        L.sbmo_prefilter_xsobel_fpga.argtypes = [u8p, sz, u8p, sz, ci, ci, ctypes.c_uint8]
+        L.sbmo_prefilter_xsobel_fpga.restype = None
+        L.sbmo_valid_roi.argtypes = [i32p, i32p, ci, ci, ci, i32p]
+        L.sbmo_valid_roi.restype = None
+        for name in ("sbmo_find_correspondence", "sbmo_find_correspondence_bruteforce"):
+            f = getattr(L, name)
+            f.argtypes = [u8p, u8p, sz, ci, ci, ci, ci, pp, i16p, sz, i32p, sz]
+            f.restype = None
+        L.sbmo_validate_disparity.argtypes = [i16p, sz, i32p, sz, ci, ci, ci, ci, ci]
+        L.sbmo_validate_disparity.restype = None
+        L.sbmo_filter_speckles.argtypes = [i16p, sz, ci, ci, ci, ci, ci]
+        L.sbmo_filter_speckles.restype = None
+        L.sbmo_compute.argtypes = [pp, u8p, sz, u8p, sz, ci, ci, i16p, sz, u8p, u8p, i16p, i32p]
+        L.sbmo_compute.restype = ci
+        L.sbmo_compute_batch.argtypes = [pp, ci, u8p, u8p, ci, ci, i16p, ci]
+        L.sbmo_compute_batch.restype = ci
+        L.sbmo_max_threads.restype = ci
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+def prefilter_xsobel(img, cap):
+    img = _u8(img)
+    out = np.empty_like(img)
+    h, w = img.shape
+    lib().sbmo_prefilter_xsobel(_p(img, ctypes.c_uint8), w, _p(out, ctypes.c_uint8), w, w, h, cap)
+    return out
+
+
+def prefilter_xsobel_fpga(img, fill=0):
+    img = _u8(img)
+    out = np.empty_like(img)
+    h, w = img.shape
+    lib().sbmo_prefilter_xsobel_fpga(_p(img, ctypes.c_uint8), w, _p(out, ctypes.c_uint8), w, w, h, fill)
+    return out
+
+
+def valid_roi(roi1, roi2, min_disparity, num_disparities, block_size):
+    a = (ctypes.c_int32 * 4)(*roi1)
+    b = (ctypes.c_int32 * 4)(*roi2)
+    o = (ctypes.c_int32 * 4)()
+    lib().sbmo_valid_roi(a, b, min_disparity, num_disparities, block_size, o)
+    return tuple(o)
+
+
+def find_correspondence(pl, pr, params, row0, row1, brute=False, want_cost=True):
+    pl, pr = _u8(pl), _u8(pr)
+    h, w = pl.shape
+    fill = (params.min_disparity - 1) * 16
+    disp = np.full((h, w), fill, dtype=np.int16)
+    cost = np.zeros((h, w), dtype=np.int32)
+    fn = lib().sbmo_find_correspondence_bruteforce if brute else lib().sbmo_find_correspondence
+    fn(_p(pl, ctypes.c_uint8), _p(pr, ctypes.c_uint8), w, w, h, row0, row1, ctypes.byref(params),
+       _p(disp, ctypes.c_int16), w, _p(cost, ctypes.c_int32) if want_cost else None, w)
+    return disp, cost
+
+
+def validate_disparity(disp, cost, min_disparity, num_disparities, disp12_max_diff):
+    disp = np.ascontiguousarray(disp, dtype=np.int16).copy()
+    cost = np.ascontiguousarray(cost, dtype=np.int32)
+    h, w = disp.shape
+    lib().sbmo_validate_disparity(_p(disp, ctypes.c_int16), w, _p(cost, ctypes.c_int32), w, w, h, min_disparity,
+                                  num_disparities, disp12_max_diff)
+    return disp
+
+
+def filter_speckles(img, new_val, max_speckle_size, max_diff):
+    img = np.ascontiguousarray(img, dtype=np.int16).copy()
+    h, w = img.shape
+    lib().sbmo_filter_speckles(_p(img, ctypes.c_int16), w, w, h, new_val, max_speckle_size, max_diff)
+    return img
+
+
+def compute(params, left, right, stages=False):
+    """cv::StereoBM::compute restated. Returns disp (int16) or (status, dict of stages) when stages=True."""
+    left, right = _u8(left), _u8(right)
+    h, w = left.shape
+    disp = np.empty((h, w), dtype=np.int16)
+    if stages:
+        pf_l = np.empty((h, w), np.uint8)
+        pf_r = np.empty((h, w), np.uint8)
+        pre = np.empty((h, w), np.int16)
+        cost = np.empty((h, w), np.int32)
+        st = lib().sbmo_compute(ctypes.byref(params), _p(left, ctypes.c_uint8), w, _p(right, ctypes.c_uint8), w, w, h,
+                                _p(disp, ctypes.c_int16), 2 * w, _p(pf_l, ctypes.c_uint8), _p(pf_r, ctypes.c_uint8),
+                                _p(pre, ctypes.c_int16), _p(cost, ctypes.c_int32))
+        return st, dict(disp=disp, pf_l=pf_l, pf_r=pf_r, pre_lr=pre, cost=cost)
+    st = lib().sbmo_compute(ctypes.byref(params), _p(left, ctypes.c_uint8), w, _p(right, ctypes.c_uint8), w, w, h,
+                            _p(disp, ctypes.c_int16), 2 * w, None, None, None, None)
+    if st != 0:
+        raise ValueError(f"oracle status {st}")
+    return disp
+
+
+def compute_status(params, width, height):
+    """Status code only (parameter validation), on dummy images."""
+    z = np.zeros((max(height, 1), max(width, 1)), np.uint8)
+    d = np.zeros((max(height, 1), max(width, 1)), np.int16)
+    return lib().sbmo_compute(ctypes.byref(params), _p(z, ctypes.c_uint8), max(width, 1), _p(z, ctypes.c_uint8),
+                              max(width, 1), width, height, _p(d, ctypes.c_int16), 2 * max(width, 1), None, None, None, None)
+
+
+def compute_batch(params, left, right, threads=None):
+    left = np.ascontiguousarray(left, dtype=np.uint8)
+    right = np.ascontiguousarray(right, dtype=np.uint8)
+    n, h, w = left.shape
+    disp = np.empty((n, h, w), np.int16)
+    if threads is None:
+        threads = max_threads()
+    st = lib().sbmo_compute_batch(ctypes.byref(params), n, _p(left, ctypes.c_uint8), _p(right, ctypes.c_uint8), w, h,
+                                  _p(disp, ctypes.c_int16), threads)
+    if st != 0:
+        raise ValueError(f"oracle status {st}")
+    return disp
+
+
+def max_threads():
+    return min(lib().sbmo_max_threads(), os.cpu_count() or 1)

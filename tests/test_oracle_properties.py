@@ -1,0 +1,201 @@
+"""Self-consistency of the CPU oracle: sliding-sum restatement vs brute force, known-answer cases, and
+independent numpy/scipy restatements of the LR check and the speckle filter."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+
+def rand_pair(rng, h, w, shift=5, noise=3):
+    base = rng.integers(0, 256, (h, w + 64), dtype=np.uint8)
+    base = ndimage.uniform_filter(base.astype(np.float32), 3).astype(np.uint8)
+    L = base[:, 32:32 + w]
+    R = np.clip(base[:, 32 + shift:32 + shift + w].astype(int) + rng.integers(-noise, noise + 1, (h, w)), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(L), np.ascontiguousarray(R)
+
+
+@pytest.mark.parametrize("h,w,nd,wsz,mind,cap,tex,uniq", [
+    (40, 64, 16, 5, 0, 31, 10, 15),
+    (37, 71, 32, 9, 0, 31, 0, 0),
+    (48, 80, 16, 15, 0, 15, 10, 10),
+    (33, 70, 16, 7, -8, 31, 5, 10),
+    (33, 70, 16, 7, 4, 63, 5, 10),
+    (30, 90, 48, 11, -60, 31, 0, 5),   # rofs > 0 branch
+    (45, 60, 32, 21, 0, 31, 10, 10),   # window wider than the left margin
+])
+def test_sliding_matches_bruteforce(oracle, h, w, nd, wsz, mind, cap, tex, uniq):
+    rng = np.random.default_rng(h * 1000 + w)
+    L, R = rand_pair(rng, h, w)
+    pl, pr = oracle.prefilter_xsobel(L, cap), oracle.prefilter_xsobel(R, cap)
+    p = oracle.make_params(nd, wsz, cap, mind, tex, uniq)
+    w2 = wsz // 2
+    for row0, row1 in ((w2, h - w2), (0, h), (3, h - 2)):
+        d1, c1 = oracle.find_correspondence(pl, pr, p, row0, row1)
+        d2, c2 = oracle.find_correspondence(pl, pr, p, row0, row1, brute=True)
+        assert np.array_equal(d1, d2)
+        valid = d1 != (mind - 1) * 16
+        assert np.array_equal(c1[valid], c2[valid])
+
+
+def test_stripe_independence(oracle):
+    """OpenCV splits the rows into stripes per thread; the result must not depend on the split."""
+    rng = np.random.default_rng(7)
+    L, R = rand_pair(rng, 60, 96)
+    pl, pr = oracle.prefilter_xsobel(L, 31), oracle.prefilter_xsobel(R, 31)
+    p = oracle.make_params(32, 9, 31, 0, 10, 10)
+    whole, _ = oracle.find_correspondence(pl, pr, p, 4, 56)
+    parts = np.full_like(whole, -16)
+    for a, b in ((4, 17), (17, 18), (18, 40), (40, 56)):
+        d, _ = oracle.find_correspondence(pl, pr, p, a, b)
+        parts[a:b] = d[a:b]
+    assert np.array_equal(whole, parts)
+
+
+def test_prefilter_borders_and_odd_height(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (9, 20), dtype=np.uint8)
+    out = oracle.prefilter_xsobel(img, 31)
+    assert (out[8] == 31).all()                       # odd H: last row is cap
+    assert (out[:, 0] == 31).all() and (out[:, -1] == 31).all()
+    i = img.astype(int)
+    dx = np.zeros_like(i)
+    dx[:, 1:-1] = i[:, 2:] - i[:, :-2]
+    ref = np.clip(dx[1] + 2 * dx[0] + dx[1], -31, 31) + 31   # reflect-101 at the top
+    assert np.array_equal(out[0, 1:-1], ref[1:-1])
+    img8 = img[:8]
+    out8 = oracle.prefilter_xsobel(img8, 31)
+    ref = np.clip(dx[6] + 2 * dx[7] + dx[6], -31, 31) + 31   # even H: reflect-101 at the bottom
+    assert np.array_equal(out8[7, 1:-1], ref[1:-1])
+    ref = np.clip(dx[2] + 2 * dx[3] + dx[4], -31, 31) + 31
+    assert np.array_equal(out8[3, 1:-1], ref[1:-1])
+
+
+def test_constant_shift_gives_constant_disparity(oracle):
+    rng = np.random.default_rng(11)
+    for shift in (3, 9, 14):
+        L, R = rand_pair(rng, 48, 128, shift=shift, noise=0)
+        p = oracle.make_params(16, 9, 31, 0, 10, 15)
+        d = oracle.compute(p, L, R)
+        roi = d[4:-4, 15 + 4 + 2:-4 - 2]
+        valid = roi[roi >= 0]
+        assert valid.size > 0.8 * roi.size
+        assert (np.abs(valid.astype(int) - shift * 16) <= 8).all()   # exact match => c = 0, |sub-pixel| <= 1/2 px
+
+
+def test_textureless_is_filtered_and_tie_prefers_largest_disparity(oracle):
+    flat = np.full((40, 64), 100, np.uint8)
+    p = oracle.make_params(16, 9, 31, 0, 10, 15)
+    assert (oracle.compute(p, flat, flat) == -16).all()
+    # texture test off, uniqueness off: every SAD is 0 -> first index wins -> largest disparity, sub-pixel 0
+    p = oracle.make_params(16, 9, 31, 0, 0, 0)
+    d = oracle.compute(p, flat, flat)
+    assert (d[4:-4, 19:-4] == 15 * 16).all()
+
+
+def test_range_does_not_fit_and_status_codes(oracle):
+    img = np.zeros((32, 40), np.uint8)
+    p = oracle.make_params(48, 5, 31, 0, 10, 15)   # lofs = 47 >= width
+    assert (oracle.compute(p, img, img) == -16).all()
+    bad = [
+        (dict(num_disparities=20), -7), (dict(num_disparities=0), -7), (dict(block_size=4), -6),
+        (dict(block_size=33), -6), (dict(prefilter_cap=0), -5), (dict(prefilter_cap=64), -5),
+        (dict(texture_threshold=-1), -8), (dict(uniqueness_ratio=-1), -9), (dict(prefilter_size=4), -4),
+        (dict(prefilter_type=2), -3),
+    ]
+    for kw, code in bad:
+        args = dict(num_disparities=16, block_size=9)
+        args.update(kw)
+        assert oracle.compute_status(oracle.make_params(**args), 40, 32) == code, kw
+
+
+def np_validate(disp, cost, mind, nd, tol_px):
+    """Independent numpy restatement of SURVEY.md Appendix A.5."""
+    disp = disp.copy()
+    h, w = disp.shape
+    inv = (mind - 1) * 16
+    for y in range(h):
+        d2 = np.full(w, inv, np.int64)
+        c2 = np.full(w, np.iinfo(np.int64).max, np.int64)
+        row = disp[y].astype(np.int64)
+        for x in range(max(mind + nd, 0), w + min(mind, 0)):
+            d = row[x]
+            if d == inv:
+                continue
+            x2 = x - ((d + 8) >> 4)
+            if c2[x2] > cost[y, x]:
+                c2[x2], d2[x2] = cost[y, x], d
+        for x in range(max(mind + nd, 0), w + min(mind, 0)):
+            d = row[x]
+            if d == inv:
+                continue
+            bad = []
+            for xx in (x - (d >> 4), x - ((d + 15) >> 4)):
+                bad.append(0 <= xx < w and d2[xx] > inv and abs(d2[xx] - d) > tol_px * 16)
+            if all(bad):
+                disp[y, x] = inv
+    return disp
+
+
+def test_validate_disparity_matches_numpy(oracle):
+    rng = np.random.default_rng(5)
+    h, w, nd = 12, 90, 32
+    disp = rng.integers(0, (nd - 1) * 16, (h, w)).astype(np.int16)
+    disp[rng.random((h, w)) < 0.3] = -16
+    cost = rng.integers(0, 50, (h, w)).astype(np.int32)       # many ties on purpose
+    for tol in (0, 1, 2):
+        got = oracle.validate_disparity(disp, cost, 0, nd, tol)
+        assert np.array_equal(got, np_validate(disp, cost, 0, nd, tol))
+    got = oracle.validate_disparity(disp - 4 * 16, cost, -4, nd, 1)
+    d4 = (disp - 64).copy()
+    assert np.array_equal(got, np_validate(d4, cost, -4, nd, 1))
+
+
+def np_speckles(img, new_val, max_size, max_diff):
+    """Independent restatement of Appendix A.6 as plain connected components (graph edges between
+    4-neighbours that are both valid and within max_diff), via scipy.sparse.csgraph."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    h, w = img.shape
+    v = img.astype(np.int64)
+    valid = v != new_val
+    idx = np.arange(h * w).reshape(h, w)
+    rows, cols = [], []
+    m = valid[:, :-1] & valid[:, 1:] & (np.abs(v[:, :-1] - v[:, 1:]) <= max_diff)
+    rows.append(idx[:, :-1][m]); cols.append(idx[:, 1:][m])
+    m = valid[:-1] & valid[1:] & (np.abs(v[:-1] - v[1:]) <= max_diff)
+    rows.append(idx[:-1][m]); cols.append(idx[1:][m])
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    g = coo_matrix((np.ones(r.size), (r, c)), shape=(h * w, h * w))
+    _, lab = connected_components(g, directed=False)
+    sizes = np.bincount(lab)
+    out = img.copy()
+    kill = valid.ravel() & (sizes[lab] <= max_size)
+    out.ravel()[kill] = new_val
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_filter_speckles_is_plain_connected_components(oracle, seed):
+    rng = np.random.default_rng(seed)
+    h, w = 50, 70
+    img = (rng.integers(0, 6, (h, w)) * 40).astype(np.int16)
+    img = ndimage.median_filter(img, 3).astype(np.int16)
+    img[rng.random((h, w)) < 0.25] = -16
+    for max_size, max_diff in ((5, 0), (20, 40), (50, 32), (1, 100)):
+        got = oracle.filter_speckles(img, -16, max_size, max_diff)
+        assert np.array_equal(got, np_speckles(img, -16, max_size, max_diff)), (max_size, max_diff)
+
+
+def test_valid_roi(oracle):
+    assert oracle.valid_roi((0, 0, 640, 480), (0, 0, 640, 480), 0, 64, 21) == (73, 10, 557, 460)
+    assert oracle.valid_roi((0, 0, 40, 30), (0, 0, 40, 30), 0, 64, 21) == (0, 0, 0, 0)
+    assert oracle.valid_roi((10, 5, 600, 400), (20, 8, 500, 300), 0, 16, 9) == (39, 12, 477, 292)
+
+
+def test_batch_matches_single(oracle):
+    rng = np.random.default_rng(9)
+    Ls, Rs = zip(*[rand_pair(rng, 40, 72) for _ in range(3)])
+    p = oracle.make_params(16, 9, 31, 0, 10, 10, 20, 16, 1)
+    got = oracle.compute_batch(p, np.stack(Ls), np.stack(Rs), threads=2)
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.compute(p, Ls[i], Rs[i]))
