@@ -1,0 +1,26 @@
+# Top-level build: the HIP engine (gfx950 only) and the CPU oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+PKG := u96-slam_amd
+CSRC := $(PKG)/csrc
+LIB := $(PKG)/lib/libsbm_hip.so
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
+SRCS := $(CSRC)/sbm_api.hip $(CSRC)/sbm_prefilter.hip $(CSRC)/sbm_sad_generic.hip $(CSRC)/sbm_sad_fast.hip $(CSRC)/sbm_post.hip
+OBJS := $(SRCS:.hip=.o)
+
+all: $(LIB) oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/sbm_common.h include/sbm.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,210 @@
+"""GPU parity: the HIP engine, called through its C-ABI (include/sbm.h), against the CPU oracle on the same
+inputs. Bit-exact (int16 disparity, uint8 prefilter, int32 cost) -- integer path, tolerance 0.
+
+The oracle is the checker only; nothing here routes the product through it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    return torch
+
+
+def run_engine(pkg, oracle, params_kw, L, R, stages=True):
+    """Runs engine (host entry point) + oracle, returns (engine dict, oracle dict)."""
+    bm = pkg.StereoBM.create(params_kw.get("num_disparities", 64), params_kw.get("block_size", 21))
+    setters = dict(prefilter_cap=bm.setPreFilterCap, min_disparity=bm.setMinDisparity,
+                   texture_threshold=bm.setTextureThreshold, uniqueness_ratio=bm.setUniquenessRatio,
+                   speckle_window_size=bm.setSpeckleWindowSize, speckle_range=bm.setSpeckleRange,
+                   disp12_max_diff=bm.setDisp12MaxDiff, roi1=bm.setROI1, roi2=bm.setROI2)
+    for k, v in params_kw.items():
+        if k in setters:
+            setters[k](v)
+    disp = bm.compute(L, R)
+    h, w = L.shape[-2:]
+    n = 1 if L.ndim == 2 else L.shape[0]
+    eng = dict(disp=disp)
+    if stages:
+        eng["pf_l"] = bm.debug_fetch(0, n, h, w)
+        eng["pf_r"] = bm.debug_fetch(1, n, h, w)
+        eng["pre_lr"] = bm.debug_fetch(3, n, h, w)
+        if params_kw.get("disp12_max_diff", -1) >= 0:
+            eng["cost"] = bm.debug_fetch(2, n, h, w)
+    p = oracle.make_params(**params_kw)
+    refs = []
+    L3 = L[None] if L.ndim == 2 else L
+    R3 = R[None] if R.ndim == 2 else R
+    for i in range(n):
+        st, ref = oracle.compute(p, L3[i], R3[i], stages=True)
+        assert st == 0
+        refs.append(ref)
+    ref = {k: np.stack([r[k] for r in refs]) for k in refs[0]}
+    return eng, ref
+
+
+def assert_stages_equal(eng, ref, params_kw):
+    n, h, w = ref["disp"].shape
+    filtered = (params_kw.get("min_disparity", 0) - 1) * 16
+    if "pf_l" in eng and ref["pre_lr"].max() > filtered:   # prefilter only runs when anything is computable
+        assert np.array_equal(eng["pf_l"], ref["pf_l"]), "prefiltered left differs"
+        assert np.array_equal(eng["pf_r"], ref["pf_r"]), "prefiltered right differs"
+    if "pre_lr" in eng:
+        bad = np.argwhere(eng["pre_lr"] != ref["pre_lr"])
+        assert bad.size == 0, f"pre-LR disparity differs at {bad[:5].tolist()} ({len(bad)} px)"
+    if "cost" in eng:
+        valid = ref["pre_lr"] != filtered
+        assert np.array_equal(eng["cost"][valid], ref["cost"][valid]), "WTA cost differs"
+    d = eng["disp"].reshape(ref["disp"].shape)
+    bad = np.argwhere(d != ref["disp"])
+    assert bad.size == 0, f"final disparity differs at {bad[:5].tolist()} ({len(bad)} px)"
+
+
+def rand_pair(rng, h, w, shift=5, noise=3):
+    from scipy import ndimage
+
+    base = rng.integers(0, 256, (h, w + 64), dtype=np.uint8)
+    base = ndimage.uniform_filter(base.astype(np.float32), 3).astype(np.uint8)
+    L = base[:, 32:32 + w]
+    R = np.clip(base[:, 32 + shift:32 + shift + w].astype(int) + rng.integers(-noise, noise + 1, (h, w)), 0, 255)
+    return np.ascontiguousarray(L), np.ascontiguousarray(R.astype(np.uint8))
+
+
+SMALL_CASES = [
+    # h, w, params
+    (40, 64, dict(num_disparities=16, block_size=5, texture_threshold=10, uniqueness_ratio=15)),
+    (37, 71, dict(num_disparities=32, block_size=9, texture_threshold=0, uniqueness_ratio=0)),
+    (48, 80, dict(num_disparities=16, block_size=15, prefilter_cap=15, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (33, 70, dict(num_disparities=16, block_size=7, min_disparity=-8, texture_threshold=5, uniqueness_ratio=10, disp12_max_diff=0)),
+    (33, 70, dict(num_disparities=16, block_size=7, min_disparity=4, prefilter_cap=63, texture_threshold=5, uniqueness_ratio=10, disp12_max_diff=2)),
+    (30, 90, dict(num_disparities=48, block_size=11, min_disparity=-60, texture_threshold=0, uniqueness_ratio=5, disp12_max_diff=1)),
+    (45, 60, dict(num_disparities=32, block_size=21, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1,
+                  speckle_window_size=20, speckle_range=16)),
+    (64, 200, dict(num_disparities=64, block_size=9, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1,
+                   speckle_window_size=50, speckle_range=32)),
+    (75, 333, dict(num_disparities=128, block_size=15, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1,
+                   speckle_window_size=50, speckle_range=32)),
+    (61, 131, dict(num_disparities=48, block_size=13, texture_threshold=3, uniqueness_ratio=20, disp12_max_diff=1)),
+    (50, 100, dict(num_disparities=16, block_size=33, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (60, 120, dict(num_disparities=32, block_size=9, roi1=(10, 5, 100, 50), roi2=(4, 2, 110, 55), disp12_max_diff=1)),
+]
+
+
+@pytest.mark.parametrize("h,w,kw", SMALL_CASES)
+def test_small_random_cases(torch_cuda, pkg, oracle, h, w, kw):
+    rng = np.random.default_rng(h * 131 + w)
+    L, R = rand_pair(rng, h, w, shift=int(rng.integers(1, 9)))
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+
+
+@pytest.mark.parametrize("wsz", [9, 21])
+def test_reference_pair_bit_exact(torch_cuda, pkg, oracle, golden, wsz):
+    """data/ref_rect_{l,r} with the call-site parameters of src/slam/src/core/main.cpp:201-212 (blockSize 21) and
+    BASELINE.json's configs[0] window (9)."""
+    kw = dict(num_disparities=64, block_size=wsz, prefilter_cap=31, texture_threshold=10, uniqueness_ratio=10,
+              speckle_window_size=50, speckle_range=32, disp12_max_diff=1)
+    eng, ref = run_engine(pkg, oracle, kw, golden["rect_l"], golden["rect_r"])
+    assert_stages_equal(eng, ref, kw)
+    if wsz == 21:
+        assert int((eng["disp"] >= 0).sum()) == 124940
+        # the engine's prefilter also satisfies the RTL-golden identity directly (reference-produced vector)
+        assert np.array_equal(eng["pf_l"][0][1:-1, 1:-1], np.maximum(golden["xsbl_l"][1:-1, 1:-1].astype(int) - 1, 0))
+        assert np.array_equal(eng["pf_r"][0][1:-1, 1:-1], np.maximum(golden["xsbl_r"][1:-1, 1:-1].astype(int) - 1, 0))
+
+
+def test_kitti_shape_batch_bit_exact(torch_cuda, pkg, oracle):
+    """BASELINE configs[1]: 1242x375, ndisp 128, 15x15, full post-filter chain, 3 synthetic pairs in one batch."""
+    from u96_slam_amd import synth
+
+    L, R = synth.make_batch(0, 3, 1242, 375, 128)
+    kw = dict(num_disparities=128, block_size=15, prefilter_cap=31, texture_threshold=10, uniqueness_ratio=10,
+              speckle_window_size=50, speckle_range=32, disp12_max_diff=1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+    assert (eng["disp"] >= 0).mean() > 0.3   # the synthetic scene is matchable
+
+
+def test_full_hd_nd256_bit_exact(torch_cuda, pkg, oracle):
+    """BASELINE configs[2] shape: 1920x1080, ndisp 256 (one pair; the oracle needs a few seconds)."""
+    from u96_slam_amd import synth
+
+    L, R = synth.make_pair(7, 1920, 1080, 256)
+    kw = dict(num_disparities=256, block_size=21, prefilter_cap=31, texture_threshold=10, uniqueness_ratio=10,
+              speckle_window_size=50, speckle_range=32, disp12_max_diff=1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R, stages=False)
+    assert_stages_equal(eng, ref, kw)
+
+
+def test_device_entry_point_matches_host_entry_point(torch_cuda, pkg, oracle):
+    torch = torch_cuda
+    from u96_slam_amd import synth
+
+    L, R = synth.make_batch(3, 4, 640, 200, 64)
+    bm = pkg.StereoBM.create(64, 9)
+    bm.setDisp12MaxDiff(1)
+    bm.setSpeckleWindowSize(50)
+    bm.setSpeckleRange(32)
+    host = bm.compute(L, R)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    dev = bm.compute(dl, dr)
+    assert dev.is_cuda and dev.dtype == torch.int16
+    assert np.array_equal(dev.cpu().numpy(), host)
+    # strided host input (cv::Mat::step larger than the row)
+    big = np.zeros((200, 700), np.uint8)
+    big[:, :640] = L[0]
+    one = bm.compute(big[:, :640], np.ascontiguousarray(R[0]))
+    assert np.array_equal(one, host[0])
+
+
+def test_degenerate_and_error_behaviour(torch_cuda, pkg, oracle):
+    img = np.zeros((32, 40), np.uint8)
+    bm = pkg.StereoBM.create(48, 5)          # disparity range does not fit: whole map FILTERED
+    assert (bm.compute(img, img) == -16).all()
+    bm = pkg.StereoBM.create(16, 9)
+    flat = np.full((40, 64), 100, np.uint8)
+    assert (bm.compute(flat, flat) == -16).all()     # textureless
+    bm.setTextureThreshold(0)
+    bm.setUniquenessRatio(0)
+    d = bm.compute(flat, flat)                        # every SAD ties at 0 -> largest disparity wins
+    assert (d[4:-4, 19:-4] == 15 * 16).all()
+    for setter, val, code in (("setNumDisparities", 20, -7), ("setBlockSize", 4, -6), ("setBlockSize", 41, -6),
+                              ("setPreFilterCap", 64, -5), ("setTextureThreshold", -1, -8),
+                              ("setUniquenessRatio", -1, -9), ("setPreFilterType", 0, -3)):
+        bm2 = pkg.StereoBM.create(16, 9)
+        getattr(bm2, setter)(val)
+        with pytest.raises(pkg.StereoBMError) as e:
+            bm2.compute(flat, flat)
+        assert e.value.code == code
+        assert oracle.compute_status(oracle.make_params(**{"num_disparities": 16, "block_size": 9,
+                                                           {"setNumDisparities": "num_disparities", "setBlockSize": "block_size",
+                                                            "setPreFilterCap": "prefilter_cap", "setTextureThreshold": "texture_threshold",
+                                                            "setUniquenessRatio": "uniqueness_ratio", "setPreFilterType": "prefilter_type"}[setter]: val}),
+                                     64, 40) == code
+    with pytest.raises(pkg.StereoBMError):
+        bm.compute(flat, flat[:, :60])
+
+
+def test_idempotent_and_deterministic(torch_cuda, pkg):
+    """Size-independent properties at a bench-sized batch: same inputs -> same outputs across calls and across
+    batch positions (pairs are independent)."""
+    from u96_slam_amd import synth
+
+    L, R = synth.make_batch(0, 2, 1242, 375, 128)
+    L8 = np.concatenate([L, L, L, L])
+    R8 = np.concatenate([R, R, R, R])
+    bm = pkg.StereoBM.create(128, 15)
+    bm.setDisp12MaxDiff(1)
+    bm.setSpeckleWindowSize(50)
+    bm.setSpeckleRange(32)
+    a = bm.compute(L8, R8)
+    b = bm.compute(L8, R8)
+    assert np.array_equal(a, b)
+    for i in range(2, 8):
+        assert np.array_equal(a[i], a[i % 2])

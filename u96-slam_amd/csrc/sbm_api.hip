@@ -1,0 +1,403 @@
+// sbm_api.hip -- C-ABI of libsbm_hip.so (declared in include/sbm.h): parameter checks, device scratch,
+// kernel orchestration.  Replaces cv::StereoBM::compute at src/slam/src/core/main.cpp:201-216.
+//
+// Stage order (same as cv::StereoBM::compute): prefilter both images -> SAD/WTA on the valid-ROI rows
+// (fast kernel on interior columns, generic kernel on the clamped border columns) -> LR check + invalid
+// row/column fill -> speckle filter.  Everything is enqueued on the handle's stream; no host sync inside.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "sbm_common.h"
+
+using namespace sbm;
+
+struct sbm_handle {
+  sbm_params p;
+  int device;
+  hipStream_t stream;
+  int last_hip;
+  // scratch, sized for (cap_n, cap_W, cap_H, cap pitch)
+  int cap_n, cap_W, cap_H, cap_pitch;
+  uint8_t *pf_l, *pf_r;
+  int16_t* disp_pre;
+  int32_t *cost, *labels, *counts;
+  // staging for the host-buffer entry points
+  int st_n, st_W, st_H;
+  uint8_t *st_l, *st_r;
+  int16_t* st_d;
+  // last launch (for sbm_debug_fetch)
+  Geom last;
+  bool have_last;
+  // profiling
+  int profiling;
+  hipEvent_t ev[8];
+  bool ev_valid[8];
+  float ms_prefilter, ms_sad, ms_border, ms_lr, ms_speckle, ms_total;
+};
+
+#define HIPCHK(h, call)                         \
+  do {                                          \
+    hipError_t e_ = (call);                     \
+    if (e_ != hipSuccess) {                     \
+      (h)->last_hip = (int)e_;                  \
+      return e_ == hipErrorOutOfMemory ? SBM_ERR_NOMEM : SBM_ERR_HIP; \
+    }                                           \
+  } while (0)
+
+extern "C" {
+
+void sbm_params_default(sbm_params* p, int num_disparities, int block_size) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->prefilter_type = SBM_PREFILTER_XSOBEL;
+  p->prefilter_size = 9;
+  p->prefilter_cap = 31;
+  p->block_size = block_size > 0 ? block_size : 21;
+  p->min_disparity = 0;
+  p->num_disparities = num_disparities > 0 ? num_disparities : 64;
+  p->texture_threshold = 10;
+  p->uniqueness_ratio = 15;
+  p->speckle_window_size = 0;
+  p->speckle_range = 0;
+  p->disp12_max_diff = -1;
+}
+
+int sbm_params_validate(const sbm_params* p, int width, int height) {
+  if (!p) return SBM_ERR_NULL;
+  if (width <= 0 || height <= 0) return SBM_ERR_SIZE;
+  if (p->prefilter_type != SBM_PREFILTER_NORMALIZED_RESPONSE && p->prefilter_type != SBM_PREFILTER_XSOBEL)
+    return SBM_ERR_PREFILTER_TYPE;
+  if (p->prefilter_size < 5 || p->prefilter_size > 255 || p->prefilter_size % 2 == 0) return SBM_ERR_PREFILTER_SIZE;
+  if (p->prefilter_cap < 1 || p->prefilter_cap > 63) return SBM_ERR_PREFILTER_CAP;
+  if (p->block_size < 5 || p->block_size > 255 || p->block_size % 2 == 0 || p->block_size >= std::min(width, height))
+    return SBM_ERR_BLOCK_SIZE;
+  if (p->num_disparities <= 0 || p->num_disparities % 16 != 0) return SBM_ERR_NUM_DISPARITIES;
+  if (p->texture_threshold < 0) return SBM_ERR_TEXTURE;
+  if (p->uniqueness_ratio < 0) return SBM_ERR_UNIQUENESS;
+  if (p->prefilter_type == SBM_PREFILTER_NORMALIZED_RESPONSE) return SBM_ERR_PREFILTER_TYPE;  // not built yet
+  return SBM_OK;
+}
+
+const char* sbm_strerror(int code) {
+  switch (code) {
+    case SBM_OK: return "ok";
+    case SBM_ERR_NULL: return "null argument";
+    case SBM_ERR_SIZE: return "bad image size or stride (all the images must have the same size)";
+    case SBM_ERR_PREFILTER_TYPE: return "preFilterType must be PREFILTER_XSOBEL (NORMALIZED_RESPONSE is not built)";
+    case SBM_ERR_PREFILTER_SIZE: return "preFilterSize must be odd and be within 5..255";
+    case SBM_ERR_PREFILTER_CAP: return "preFilterCap must be within 1..63";
+    case SBM_ERR_BLOCK_SIZE: return "SADWindowSize must be odd, be within 5..255 and be not larger than image width or height";
+    case SBM_ERR_NUM_DISPARITIES: return "numDisparities must be positive and divisible by 16";
+    case SBM_ERR_TEXTURE: return "texture threshold must be non-negative";
+    case SBM_ERR_UNIQUENESS: return "uniqueness ratio must be non-negative";
+    case SBM_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU backend)";
+    case SBM_ERR_HIP: return "HIP runtime error (see sbm_last_hip_error)";
+    case SBM_ERR_NOMEM: return "out of memory";
+    case SBM_ERR_UNSUPPORTED: return "configuration outside this build's limits";
+    case SBM_ERR_BATCH: return "batch count must be positive";
+    default: return "unknown status";
+  }
+}
+
+int sbm_version(void) { return SBM_VERSION_MAJOR * 1000 + SBM_VERSION_MINOR; }
+
+static void free_scratch(sbm_handle* h) {
+  hipFree(h->pf_l); hipFree(h->pf_r); hipFree(h->disp_pre); hipFree(h->cost); hipFree(h->labels); hipFree(h->counts);
+  h->pf_l = h->pf_r = nullptr; h->disp_pre = nullptr; h->cost = h->labels = h->counts = nullptr;
+  h->cap_n = h->cap_W = h->cap_H = h->cap_pitch = 0;
+}
+
+static void free_staging(sbm_handle* h) {
+  hipFree(h->st_l); hipFree(h->st_r); hipFree(h->st_d);
+  h->st_l = h->st_r = nullptr; h->st_d = nullptr; h->st_n = h->st_W = h->st_H = 0;
+}
+
+int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
+  if (!out || !p) return SBM_ERR_NULL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SBM_ERR_NO_DEVICE;
+  sbm_handle* h = new (std::nothrow) sbm_handle();
+  if (!h) return SBM_ERR_NOMEM;
+  memset(h, 0, sizeof(*h));
+  h->p = *p;
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return SBM_ERR_NO_DEVICE;
+  }
+  for (int i = 0; i < 8; i++) h->ev_valid[i] = hipEventCreate(&h->ev[i]) == hipSuccess;
+  *out = h;
+  return SBM_OK;
+}
+
+void sbm_destroy(sbm_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  free_scratch(h);
+  free_staging(h);
+  for (int i = 0; i < 8; i++)
+    if (h->ev_valid[i]) hipEventDestroy(h->ev[i]);
+  hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int sbm_set_params(sbm_handle* h, const sbm_params* p) {
+  if (!h || !p) return SBM_ERR_NULL;
+  h->p = *p;
+  return SBM_OK;
+}
+
+int sbm_get_params(const sbm_handle* h, sbm_params* p) {
+  if (!h || !p) return SBM_ERR_NULL;
+  *p = h->p;
+  return SBM_OK;
+}
+
+void* sbm_stream(sbm_handle* h) { return h ? (void*)h->stream : nullptr; }
+int sbm_last_hip_error(const sbm_handle* h) { return h ? h->last_hip : 0; }
+
+int sbm_synchronize(sbm_handle* h) {
+  if (!h) return SBM_ERR_NULL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_set_profiling(sbm_handle* h, int enabled) {
+  if (!h) return SBM_ERR_NULL;
+  h->profiling = enabled != 0;
+  return SBM_OK;
+}
+
+// cv getValidDisparityROI (calib3d stereosgbm.cpp) with cv::StereoBM's "empty rect = whole image" substitution.
+static void valid_roi(const sbm_params& p, int W, int H, int roi[4]) {
+  int full[4] = {0, 0, W, H};
+  const int* r1 = (p.roi1[2] > 0 && p.roi1[3] > 0) ? p.roi1 : full;
+  const int* r2 = (p.roi2[2] > 0 && p.roi2[3] > 0) ? p.roi2 : full;
+  const int sw2 = p.block_size / 2, maxd = p.min_disparity + p.num_disparities - 1;
+  const int xmin = std::max(r1[0], r2[0] + maxd) + sw2;
+  const int xmax = std::min(r1[0] + r1[2], r2[0] + r2[2]) - sw2;
+  const int ymin = std::max(r1[1], r2[1]) + sw2;
+  const int ymax = std::min(r1[1] + r1[3], r2[1] + r2[3]) - sw2;
+  if (xmax - xmin > 0 && ymax - ymin > 0) {
+    roi[0] = xmin; roi[1] = ymin; roi[2] = xmax - xmin; roi[3] = ymax - ymin;
+  } else {
+    roi[0] = roi[1] = roi[2] = roi[3] = 0;
+  }
+}
+
+static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool need_cost, bool need_speckle) {
+  const bool fits = n <= h->cap_n && W == h->cap_W && H == h->cap_H && pitch == h->cap_pitch && h->pf_l;
+  if (!fits) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    free_scratch(h);
+    const size_t npix = (size_t)n * W * H, pfbytes = (size_t)n * pitch * H + 64;
+    HIPCHK(h, hipMalloc((void**)&h->pf_l, pfbytes));
+    HIPCHK(h, hipMalloc((void**)&h->pf_r, pfbytes));
+    HIPCHK(h, hipMalloc((void**)&h->disp_pre, npix * sizeof(int16_t)));
+    // padding bytes must read as 0 (the masked value of the fast kernel); the prefilter never writes them
+    HIPCHK(h, hipMemsetAsync(h->pf_l, 0, pfbytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->pf_r, 0, pfbytes, h->stream));
+    h->cap_n = n; h->cap_W = W; h->cap_H = H; h->cap_pitch = pitch;
+  }
+  const size_t npix = (size_t)h->cap_n * W * H;
+  if (need_cost && !h->cost) HIPCHK(h, hipMalloc((void**)&h->cost, npix * sizeof(int32_t)));
+  if (need_speckle && !h->labels) {
+    HIPCHK(h, hipMalloc((void**)&h->labels, npix * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc((void**)&h->counts, npix * sizeof(int32_t)));
+  }
+  return SBM_OK;
+}
+
+static inline void mark(sbm_handle* h, int i) {
+  if (h->profiling && h->ev_valid[i]) hipEventRecord(h->ev[i], h->stream);
+}
+
+int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, int width, int height,
+                       void* d_disp, int sync) {
+  if (!h || !d_left || !d_right || !d_disp) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  int st = sbm_params_validate(&h->p, width, height);
+  if (st != SBM_OK) return st;
+  if (n > 32767 || height > 65535) return SBM_ERR_UNSUPPORTED;
+  const sbm_params& p = h->p;
+  if (p.num_disparities > 4096) return SBM_ERR_UNSUPPORTED;
+  HIPCHK(h, hipSetDevice(h->device));
+
+  Geom g;
+  memset(&g, 0, sizeof(g));
+  g.W = width; g.H = height; g.n = n;
+  g.nd = p.num_disparities; g.mindisp = p.min_disparity; g.wsz = p.block_size; g.w2 = p.block_size / 2;
+  g.cap = p.prefilter_cap; g.tex = p.texture_threshold; g.uniq = p.uniqueness_ratio;
+  g.filtered = (p.min_disparity - 1) * 16;
+  g.lofs = std::max(g.nd - 1 + g.mindisp, 0);
+  g.rofs = -std::min(g.nd - 1 + g.mindisp, 0);
+  g.width1 = width - g.rofs - g.nd + 1;
+  g.xend = std::min(g.width1, width - g.lofs);
+  g.want_cost = p.disp12_max_diff >= 0;
+  // padded prefiltered planes: the fast kernel stages 16-byte pieces that may start up to nd+64 bytes left of
+  // column 0 and end up to 96 bytes right of column W-1
+  g.padl = ((g.nd + 64 + 63) / 64) * 64;
+  g.pitch = ((g.padl + width + 128 + 63) / 64) * 64;
+  g.plane = g.pitch * height;
+  int16_t* out = (int16_t*)d_disp;
+  const size_t npix = (size_t)n * width * height;
+
+  int roi[4];
+  valid_roi(p, width, height, roi);
+  g.row0 = std::max(roi[1], 0); g.row1 = std::min(roi[1] + roi[3], height);
+  g.col0 = std::max(std::min(roi[0], width), 0); g.col1 = std::max(std::min(roi[0] + roi[2], width), 0);
+  const bool range_fits = !(g.lofs >= width || g.rofs >= width || g.width1 < 1);
+  const bool any_rows = range_fits && roi[2] > 0 && roi[3] > 0 && g.row1 > g.row0;
+  if (!any_rows) { g.row0 = g.row1 = 0; }
+  const bool speckle = p.speckle_range >= 0 && p.speckle_window_size > 0;
+
+  st = ensure_scratch(h, n, width, height, g.pitch, g.want_cost, speckle);
+  if (st != SBM_OK) return st;
+  h->last = g; h->have_last = true;
+
+  mark(h, 0);
+  if (any_rows) {
+    HIPCHK(h, launch_prefilter((const uint8_t*)d_left, (const uint8_t*)d_right, h->pf_l, h->pf_r, g, h->stream));
+  }
+  mark(h, 1);
+  if (any_rows) {
+    // every computed column (valid or not) must hold a defined value before the LR check reads it
+    int fa = 0, fb = 0;
+    if (sad_fast_supported(g)) {
+      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &fa, &fb, h->stream));
+    }
+    mark(h, 2);
+    // columns left and right of the fast range: clamped windows (or everything when the fast path is off).
+    // They only matter if they can influence the output: through the LR check or when inside the valid ROI.
+    const bool borders_visible = g.want_cost || g.col0 < g.lofs + fa || g.col1 > g.lofs + fb;
+    if (fb <= fa) {
+      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
+    } else if (borders_visible) {
+      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, fa, h->stream));
+      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fb, g.xend, h->stream));
+    }
+  } else {
+    mark(h, 2);
+  }
+  mark(h, 3);
+  HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
+  mark(h, 4);
+  if (speckle) HIPCHK(h, launch_speckle(out, h->labels, h->counts, g, p.speckle_window_size, p.speckle_range, h->stream));
+  mark(h, 5);
+  (void)npix;
+  if (sync || h->profiling) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->profiling) {
+      auto el = [&](int a, int b) { float ms = 0.f; if (h->ev_valid[a] && h->ev_valid[b]) hipEventElapsedTime(&ms, h->ev[a], h->ev[b]); return ms; };
+      h->ms_prefilter = el(0, 1); h->ms_sad = el(1, 2); h->ms_border = el(2, 3); h->ms_lr = el(3, 4);
+      h->ms_speckle = el(4, 5); h->ms_total = el(0, 5);
+    }
+  }
+  return SBM_OK;
+}
+
+int sbm_get_profile(sbm_handle* h, const char* name, float* ms) {
+  if (!h || !name || !ms) return SBM_ERR_NULL;
+  if (!strcmp(name, "prefilter")) *ms = h->ms_prefilter;
+  else if (!strcmp(name, "sad")) *ms = h->ms_sad;
+  else if (!strcmp(name, "border")) *ms = h->ms_border;
+  else if (!strcmp(name, "lrcheck")) *ms = h->ms_lr;
+  else if (!strcmp(name, "speckle")) *ms = h->ms_speckle;
+  else if (!strcmp(name, "total")) *ms = h->ms_total;
+  else return SBM_ERR_UNSUPPORTED;
+  return SBM_OK;
+}
+
+int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes) {
+  if (!h || !dst) return SBM_ERR_NULL;
+  if (!h->have_last) return SBM_ERR_UNSUPPORTED;
+  const Geom& g = h->last;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t npix = (size_t)g.n * g.W * g.H;
+  if (which == 0 || which == 1) {
+    if (dst_bytes < npix) return SBM_ERR_SIZE;
+    const uint8_t* src = which == 0 ? h->pf_l : h->pf_r;
+    HIPCHK(h, hipMemcpy2D(dst, g.W, src + g.padl, g.pitch, g.W, (size_t)g.n * g.H, hipMemcpyDeviceToHost));
+    uint8_t* d = (uint8_t*)dst;
+    for (size_t i = 0; i < npix; i++) d[i] = (uint8_t)(d[i] - kPfBias);
+    return SBM_OK;
+  }
+  if (which == 2) {
+    if (!h->cost) return SBM_ERR_UNSUPPORTED;
+    if (dst_bytes < npix * sizeof(int32_t)) return SBM_ERR_SIZE;
+    HIPCHK(h, hipMemcpy(dst, h->cost, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return SBM_OK;
+  }
+  if (which == 3) {
+    if (dst_bytes < npix * sizeof(int16_t)) return SBM_ERR_SIZE;
+    HIPCHK(h, hipMemcpy(dst, h->disp_pre, npix * sizeof(int16_t), hipMemcpyDeviceToHost));
+    // rows outside the valid ROI and the never-matchable column bands are not produced on the device
+    int16_t* d = (int16_t*)dst;
+    for (int i = 0; i < g.n; i++)
+      for (int y = 0; y < g.H; y++) {
+        int16_t* row = d + ((size_t)i * g.H + y) * g.W;
+        const bool live = y >= g.row0 && y < g.row1;
+        for (int x = 0; x < g.W; x++)
+          if (!live || x < g.lofs || x >= g.lofs + g.xend) row[x] = (int16_t)g.filtered;
+      }
+    return SBM_OK;
+  }
+  return SBM_ERR_UNSUPPORTED;
+}
+
+static int ensure_staging(sbm_handle* h, int n, int W, int H) {
+  if (n <= h->st_n && W == h->st_W && H == h->st_H && h->st_l) return SBM_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_staging(h);
+  const size_t npix = (size_t)n * W * H;
+  HIPCHK(h, hipMalloc((void**)&h->st_l, npix + 64));
+  HIPCHK(h, hipMalloc((void**)&h->st_r, npix + 64));
+  HIPCHK(h, hipMalloc((void**)&h->st_d, npix * sizeof(int16_t)));
+  h->st_n = n; h->st_W = W; h->st_H = H;
+  return SBM_OK;
+}
+
+int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t left_stride, const uint8_t* const* right,
+                      size_t right_stride, int width, int height, int16_t* const* disp, size_t disp_stride) {
+  if (!h || !left || !right || !disp) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  int st = sbm_params_validate(&h->p, width, height);
+  if (st != SBM_OK) return st;
+  if (left_stride < (size_t)width || right_stride < (size_t)width || disp_stride < (size_t)width * 2) return SBM_ERR_SIZE;
+  for (int i = 0; i < n; i++)
+    if (!left[i] || !right[i] || !disp[i]) return SBM_ERR_NULL;
+  HIPCHK(h, hipSetDevice(h->device));
+  st = ensure_staging(h, n, width, height);
+  if (st != SBM_OK) return st;
+  const size_t npix1 = (size_t)width * height;
+  for (int i = 0; i < n; i++) {
+    HIPCHK(h, hipMemcpy2DAsync(h->st_l + i * npix1, width, left[i], left_stride, width, height, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->st_r + i * npix1, width, right[i], right_stride, width, height, hipMemcpyHostToDevice, h->stream));
+  }
+  st = sbm_compute_device(h, n, h->st_l, h->st_r, width, height, h->st_d, 0);
+  if (st != SBM_OK) return st;
+  for (int i = 0; i < n; i++)
+    HIPCHK(h, hipMemcpy2DAsync(disp[i], disp_stride, h->st_d + i * npix1, (size_t)width * 2, (size_t)width * 2, height,
+                               hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_compute(sbm_handle* h, const uint8_t* left, size_t left_stride, const uint8_t* right, size_t right_stride, int width,
+                int height, int16_t* disp, size_t disp_stride) {
+  const uint8_t* l[1] = {left};
+  const uint8_t* r[1] = {right};
+  int16_t* d[1] = {disp};
+  if (!left || !right || !disp) return SBM_ERR_NULL;
+  return sbm_compute_batch(h, 1, l, left_stride, r, right_stride, width, height, d, disp_stride);
+}
+
+}  // extern "C"

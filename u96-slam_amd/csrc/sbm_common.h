@@ -1,0 +1,53 @@
+// sbm_common.h -- shared declarations of the HIP stereo block-matching engine (internal, gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sbm.h"
+
+namespace sbm {
+
+// Geometry of one launch, derived on the host from sbm_params and the image size. Naming follows
+// cv::StereoBM (calib3d stereobm.cpp): lofs/rofs/width1, buffer index d <-> true disparity nd-1-d+mindisp.
+struct Geom {
+  int W, H;            // image size
+  int n;               // pairs in the batch
+  int pitch;           // byte pitch of the padded prefiltered planes
+  int padl;            // bytes of left padding in front of column 0 of a prefiltered row
+  int plane;           // bytes per prefiltered plane (pitch * H)
+  int nd, mindisp, wsz, w2, cap;
+  int lofs, rofs, width1, xend;  // xend = min(width1, W - lofs): computed columns are X = lofs + x, x in [0,xend)
+  int tex, uniq;
+  int filtered;        // (mindisp - 1) * 16
+  int row0, row1;      // valid-ROI rows [row0,row1)
+  int col0, col1;      // valid-ROI columns [col0,col1)
+  int want_cost;       // disp12_max_diff >= 0
+};
+
+// Prefiltered planes store value+1 (range 1..2*cap+1 <= 127) so that 0 can act as the "masked byte" of
+// v_mqsad_pk_u16_u8; padding bytes are 0. sbm_debug_fetch() removes the bias again.
+constexpr int kPfBias = 1;
+
+hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
+                            const Geom& g, hipStream_t s);
+
+// Generic SAD/WTA for output columns x in [xa,xb) (x relative to lofs) and rows [row0,row1): any block size,
+// any disparity count, clamped border windows. Used for the border columns and as the fallback path.
+hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
+                              int xa, int xb, hipStream_t s);
+
+// Fast path (interior columns, block size multiple of 3 up to 21, 16-bit sums). Returns hipErrorNotSupported
+// when the configuration is outside its envelope; *xa,*xb receive the column range it covered.
+bool sad_fast_supported(const Geom& g);
+hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
+                           int* xa, int* xb, hipStream_t s);
+
+// Left-right consistency (cv validateDisparity) + invalid rows/columns fill. Reads disp_pre/cost, writes disp_out.
+hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
+                          int disp12_max_diff, hipStream_t s);
+
+// cv filterSpeckles as parallel connected components (union-find). labels/counts: n*H*W int32 scratch each.
+hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
+                          hipStream_t s);
+
+}  // namespace sbm

@@ -1,0 +1,182 @@
+// sbm_post.hip -- post-filters of the disparity map: left-right consistency + ROI fill, speckle filter. gfx950.
+//
+// Device counterparts of validateDisparity / filterSpeckles (OpenCV calib3d stereosgbm.cpp), switched on by
+// setDisp12MaxDiff(1), setSpeckleWindowSize(50), setSpeckleRange(32) at src/slam/src/core/main.cpp:210-212.
+// Neither has an FPGA twin in the reference.
+#include "sbm_common.h"
+
+namespace sbm {
+
+// ---------------------------------------------------------------------------------------------------------
+// LR check.  cv semantics per row: pass 1 walks x upward and lets each valid left pixel claim the right-view
+// column x2 = x - round(d) if its cost is strictly smaller than the current claimant's  => the winner of a slot is
+// the claimant with minimum (cost, x).  That is order-free: one LDS atomicMin on the 64-bit key cost<<32|x per
+// pixel.  Pass 2 is per-pixel.  One workgroup owns one image row; the same kernel writes the never-valid rows and
+// columns (outside the valid ROI) as FILTERED, which cv does after validateDisparity.
+// ---------------------------------------------------------------------------------------------------------
+struct LrArgs {
+  const int16_t* disp_pre;
+  const int32_t* cost;
+  int16_t* disp_out;
+  int W, H, mindisp, nd, tol, filtered, row0, row1, col0, col1, do_lr;
+  int cx0, cx1;  // columns [cx0,cx1) of disp_pre were computed; the rest reads as FILTERED
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned long long lr_keys[];
+
+__global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
+  const int y = blockIdx.x;
+  const size_t base = ((size_t)blockIdx.y * a.H + y) * a.W;
+  int16_t* out = a.disp_out + base;
+  if (y < a.row0 || y >= a.row1) {
+    for (int x = threadIdx.x; x < a.W; x += 256) out[x] = (int16_t)a.filtered;
+    return;
+  }
+  const int16_t* dp = a.disp_pre + base;
+  if (!a.do_lr) {
+    const int lo = max(a.col0, a.cx0), hi = min(a.col1, a.cx1);
+    for (int x = threadIdx.x; x < a.W; x += 256) out[x] = (x >= lo && x < hi) ? dp[x] : (int16_t)a.filtered;
+    return;
+  }
+  const int32_t* cp = a.cost + base;
+  const int INV = a.filtered;
+  const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(a.W + min(a.mindisp, 0), a.cx1);
+  for (int x = threadIdx.x; x < a.W; x += 256) lr_keys[x] = ~0ull;
+  __syncthreads();
+  for (int x = minX1 + threadIdx.x; x < maxX1; x += 256) {
+    const int d = dp[x];
+    if (d == INV) continue;
+    const int x2 = x - ((d + 8) >> 4);
+    if (x2 >= 0 && x2 < a.W)
+      atomicMin(&lr_keys[x2], ((unsigned long long)(unsigned)cp[x] << 32) | (unsigned)x);
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < a.W; x += 256) {
+    int d = (x >= a.cx0 && x < a.cx1) ? dp[x] : INV;
+    if (x < a.col0 || x >= a.col1) {
+      d = INV;
+    } else if (d != INV && x >= minX1 && x < maxX1) {
+      const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
+      bool bad_a = false, bad_b = false;
+      if (xa >= 0 && xa < a.W) {
+        const unsigned long long k = lr_keys[xa];
+        if (k != ~0ull) {
+          const int d2 = dp[(int)(k & 0xffffffffu)];
+          bad_a = abs(d2 - d) > a.tol;
+        }
+      }
+      if (xb >= 0 && xb < a.W) {
+        const unsigned long long k = lr_keys[xb];
+        if (k != ~0ull) {
+          const int d2 = dp[(int)(k & 0xffffffffu)];
+          bad_b = abs(d2 - d) > a.tol;
+        }
+      }
+      if (bad_a && bad_b) d = INV;
+    }
+    out[x] = (int16_t)d;
+  }
+}
+
+hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
+                          int disp12_max_diff, hipStream_t s) {
+  LrArgs a;
+  a.disp_pre = disp_pre; a.cost = cost; a.disp_out = disp_out;
+  a.W = g.W; a.H = g.H; a.mindisp = g.mindisp; a.nd = g.nd; a.tol = disp12_max_diff * 16; a.filtered = g.filtered;
+  a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
+  a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;
+  size_t lds = a.do_lr ? (size_t)g.W * sizeof(unsigned long long) : 0;
+  hipLaunchKernelGGL(lrcheck_kernel, dim3(g.H, g.n), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Speckle filter.  cv's raster-order flood fill yields plain 4-connected components of the relation
+// "both != newVal and |a-b| <= maxDiff" (order-independent), so it is computed here with
+// a lock-free union-find: init -> merge right/down edges (atomicMin hooks) -> flatten + count -> threshold.
+// Labels are pixel indices within the pair's own plane.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(const int* L, int i) {
+  int r = i;
+  for (;;) {
+    const int p = __hip_atomic_load(L + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == r) return r;
+    r = p;
+  }
+}
+
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+  for (;;) {
+    a = uf_find(L, a);
+    b = uf_find(L, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(L + b, a);
+    if (old == b) return;
+    b = old;
+  }
+}
+
+__global__ void __launch_bounds__(256) speckle_init_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
+                                                            int* __restrict__ counts, int npix, int newval) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const size_t o = (size_t)blockIdx.y * npix + i;
+  labels[o] = disp[o] != newval ? i : -1;
+  counts[o] = 0;
+}
+
+__global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
+                                                             int W, int H, int newval, int maxdiff) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int npix = W * H;
+  if (i >= npix) return;
+  const size_t po = (size_t)blockIdx.y * npix;
+  const int16_t* d = disp + po;
+  int* L = labels + po;
+  const int v = d[i];
+  if (v == newval) return;
+  const int x = i % W, y = i / W;
+  if (x + 1 < W) {
+    const int u = d[i + 1];
+    if (u != newval && abs(v - u) <= maxdiff) uf_union(L, i, i + 1);
+  }
+  if (y + 1 < H) {
+    const int u = d[i + W];
+    if (u != newval && abs(v - u) <= maxdiff) uf_union(L, i, i + W);
+  }
+}
+
+__global__ void __launch_bounds__(256) speckle_count_kernel(int* __restrict__ labels, int* __restrict__ counts, int npix) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const size_t po = (size_t)blockIdx.y * npix;
+  int* L = labels + po;
+  if (L[i] < 0) return;
+  const int r = uf_find(L, i);
+  L[i] = r;  // roots are final (merge kernel finished), so this is a pure shortcut
+  atomicAdd(counts + po + r, 1);
+}
+
+__global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict__ disp, const int* __restrict__ labels,
+                                                             const int* __restrict__ counts, int npix, int newval,
+                                                             int maxsize) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const size_t po = (size_t)blockIdx.y * npix;
+  const int r = labels[po + i];
+  if (r >= 0 && counts[po + r] <= maxsize) disp[po + i] = (int16_t)newval;
+}
+
+hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
+                          hipStream_t s) {
+  const int npix = g.W * g.H;
+  dim3 grid((npix + 255) / 256, g.n);
+  hipLaunchKernelGGL(speckle_init_kernel, grid, dim3(256), 0, s, disp, labels, counts, npix, g.filtered);
+  hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
+  hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, labels, counts, npix);
+  hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, npix, g.filtered, max_size);
+  return hipGetLastError();
+}
+
+}  // namespace sbm

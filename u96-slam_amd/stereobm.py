@@ -1,0 +1,251 @@
+"""Host-side mirror of cv::StereoBM over the C-ABI of lib/libsbm_hip.so (include/sbm.h).
+
+Same names, argument meaning and error behaviour as the interface used at
+src/slam/src/core/main.cpp:201-215 of the reference:
+
+    bm = StereoBM.create(16, 9); bm.setPreFilterCap(31); bm.setBlockSize(21); ...; disp = bm.compute(left, right)
+
+`compute` accepts numpy uint8 images (host path, sbm_compute / sbm_compute_batch) or torch CUDA uint8 tensors
+(device path, sbm_compute_device; torch is used for device memory only). Parameter errors raise StereoBMError
+with the status code and OpenCV's message, where cv::StereoBM::compute would throw cv::Error.
+"""
+import ctypes
+import pathlib
+
+import numpy as np
+
+PREFILTER_NORMALIZED_RESPONSE = 0
+PREFILTER_XSOBEL = 1
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_LIB = None
+
+
+class SbmParams(ctypes.Structure):
+    """`sbm_params` of include/sbm.h."""
+
+    _fields_ = [
+        ("prefilter_type", ctypes.c_int32), ("prefilter_size", ctypes.c_int32), ("prefilter_cap", ctypes.c_int32),
+        ("block_size", ctypes.c_int32), ("min_disparity", ctypes.c_int32), ("num_disparities", ctypes.c_int32),
+        ("texture_threshold", ctypes.c_int32), ("uniqueness_ratio", ctypes.c_int32),
+        ("speckle_window_size", ctypes.c_int32), ("speckle_range", ctypes.c_int32), ("disp12_max_diff", ctypes.c_int32),
+        ("roi1", ctypes.c_int32 * 4), ("roi2", ctypes.c_int32 * 4),
+    ]
+
+
+class StereoBMError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"sbm status {code}: {message}")
+        self.code = code
+
+
+def library_path():
+    return _HERE / "lib" / "libsbm_hip.so"
+
+
+def load_library():
+    """Load lib/libsbm_hip.so. Fails loudly when it has not been built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # torch ships its own HIP runtime; when both live in one process it must be the first one loaded so that
+    # libsbm_hip.so binds to the same runtime (device memory and streams are shared with torch).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = library_path()
+    if not path.exists():
+        raise ImportError(f"{path} is missing: build it with `make` (or __graft_entry__.build()); "
+                          "this package has no CPU fallback")
+    L = ctypes.CDLL(str(path))
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    pp = ctypes.POINTER(SbmParams)
+    L.sbm_params_default.argtypes = [pp, ci, ci]
+    L.sbm_params_default.restype = None
+    L.sbm_params_validate.argtypes = [pp, ci, ci]
+    L.sbm_create.argtypes = [ctypes.POINTER(vp), pp, ci]
+    L.sbm_destroy.argtypes = [vp]
+    L.sbm_destroy.restype = None
+    L.sbm_set_params.argtypes = [vp, pp]
+    L.sbm_get_params.argtypes = [vp, pp]
+    L.sbm_compute.argtypes = [vp, vp, sz, vp, sz, ci, ci, vp, sz]
+    L.sbm_compute_batch.argtypes = [vp, ci, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz, ci, ci, ctypes.POINTER(vp), sz]
+    L.sbm_compute_device.argtypes = [vp, ci, vp, vp, ci, ci, vp, ci]
+    L.sbm_synchronize.argtypes = [vp]
+    L.sbm_debug_fetch.argtypes = [vp, ci, vp, sz]
+    L.sbm_set_profiling.argtypes = [vp, ci]
+    L.sbm_get_profile.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
+    L.sbm_stream.argtypes = [vp]
+    L.sbm_stream.restype = vp
+    L.sbm_strerror.argtypes = [ci]
+    L.sbm_strerror.restype = ctypes.c_char_p
+    L.sbm_last_hip_error.argtypes = [vp]
+    L.sbm_version.restype = ci
+    _LIB = L
+    return L
+
+
+def _check(code, handle=None):
+    if code != 0:
+        L = load_library()
+        msg = L.sbm_strerror(code).decode()
+        if code == -21 and handle:
+            msg += f" (hipError {L.sbm_last_hip_error(handle)})"
+        raise StereoBMError(code, msg)
+
+
+class StereoBM:
+    """cv::StereoBM look-alike. One instance owns one device handle (stream + scratch); not thread-safe."""
+
+    def __init__(self, numDisparities=0, blockSize=21, device=0):
+        L = load_library()
+        self._L = L
+        self._p = SbmParams()
+        L.sbm_params_default(ctypes.byref(self._p), numDisparities, blockSize)
+        self._h = ctypes.c_void_p()
+        self._device = device
+        _check(L.sbm_create(ctypes.byref(self._h), ctypes.byref(self._p), device))
+
+    @staticmethod
+    def create(numDisparities=0, blockSize=21, device=0):
+        return StereoBM(numDisparities, blockSize, device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.sbm_destroy(h)
+            self._h = None
+
+    # ---- the cv::StereoBM / cv::StereoMatcher setters and getters -------------------------------------------
+    def _set(self, name, v):
+        setattr(self._p, name, int(v))
+        _check(self._L.sbm_set_params(self._h, ctypes.byref(self._p)), self._h)
+
+    def setPreFilterType(self, v): self._set("prefilter_type", v)
+    def setPreFilterSize(self, v): self._set("prefilter_size", v)
+    def setPreFilterCap(self, v): self._set("prefilter_cap", v)
+    def setBlockSize(self, v): self._set("block_size", v)
+    def setMinDisparity(self, v): self._set("min_disparity", v)
+    def setNumDisparities(self, v): self._set("num_disparities", v)
+    def setTextureThreshold(self, v): self._set("texture_threshold", v)
+    def setUniquenessRatio(self, v): self._set("uniqueness_ratio", v)
+    def setSpeckleWindowSize(self, v): self._set("speckle_window_size", v)
+    def setSpeckleRange(self, v): self._set("speckle_range", v)
+    def setDisp12MaxDiff(self, v): self._set("disp12_max_diff", v)
+
+    def setROI1(self, rect):
+        self._p.roi1[:] = [int(v) for v in rect]
+        _check(self._L.sbm_set_params(self._h, ctypes.byref(self._p)), self._h)
+
+    def setROI2(self, rect):
+        self._p.roi2[:] = [int(v) for v in rect]
+        _check(self._L.sbm_set_params(self._h, ctypes.byref(self._p)), self._h)
+
+    def getPreFilterType(self): return self._p.prefilter_type
+    def getPreFilterSize(self): return self._p.prefilter_size
+    def getPreFilterCap(self): return self._p.prefilter_cap
+    def getBlockSize(self): return self._p.block_size
+    def getMinDisparity(self): return self._p.min_disparity
+    def getNumDisparities(self): return self._p.num_disparities
+    def getTextureThreshold(self): return self._p.texture_threshold
+    def getUniquenessRatio(self): return self._p.uniqueness_ratio
+    def getSpeckleWindowSize(self): return self._p.speckle_window_size
+    def getSpeckleRange(self): return self._p.speckle_range
+    def getDisp12MaxDiff(self): return self._p.disp12_max_diff
+    def getROI1(self): return tuple(self._p.roi1)
+    def getROI2(self): return tuple(self._p.roi2)
+
+    def params(self):
+        q = SbmParams()
+        ctypes.memmove(ctypes.byref(q), ctypes.byref(self._p), ctypes.sizeof(SbmParams))
+        return q
+
+    # ---- compute ----------------------------------------------------------------------------------------------
+    def compute(self, left, right, disparity=None):
+        """cv::StereoBM::compute. numpy (H,W) or (n,H,W) uint8 -> numpy int16; torch CUDA uint8 -> torch CUDA int16."""
+        if isinstance(left, np.ndarray):
+            return self._compute_host(left, right, disparity)
+        return self.compute_device(left, right, disparity)
+
+    def _compute_host(self, left, right, disparity):
+        if left.shape != right.shape:
+            raise StereoBMError(-2, "All the images must have the same size")
+        if left.dtype != np.uint8 or right.dtype != np.uint8:
+            raise StereoBMError(-2, "Both input images must have CV_8UC1")
+        single = left.ndim == 2
+        L3 = left[None] if single else left
+        R3 = right[None] if single else right
+        if L3.ndim != 3:
+            raise StereoBMError(-2, "expected (H,W) or (n,H,W) images")
+        n, h, w = L3.shape
+        # honour arbitrary row strides like cv::Mat::step, but rows themselves must be dense
+        def rows(a):
+            if a.strides[-1] != 1:
+                a = np.ascontiguousarray(a)
+            return a
+        L3, R3 = rows(L3), rows(R3)
+        out = disparity if disparity is not None else np.empty(L3.shape, np.int16)
+        out3 = out[None] if out.ndim == 2 else out
+        assert out3.shape == L3.shape and out3.dtype == np.int16 and out3.strides[-1] == 2
+        vp = ctypes.c_void_p
+        lp = (vp * n)(*[L3[i].ctypes.data for i in range(n)])
+        rp = (vp * n)(*[R3[i].ctypes.data for i in range(n)])
+        dp = (vp * n)(*[out3[i].ctypes.data for i in range(n)])
+        _check(self._L.sbm_compute_batch(self._h, n, lp, L3.strides[-2], rp, R3.strides[-2], w, h, dp, out3.strides[-2]),
+               self._h)
+        return out[0] if (single and disparity is None) else out
+
+    def compute_device(self, left, right, disparity=None, sync=True):
+        """Device-resident batch: torch CUDA uint8 tensors (n,H,W) or (H,W), contiguous. Returns a torch int16 tensor."""
+        import torch
+
+        if left.shape != right.shape:
+            raise StereoBMError(-2, "All the images must have the same size")
+        if left.dtype != torch.uint8 or right.dtype != torch.uint8 or not left.is_cuda or not right.is_cuda:
+            raise StereoBMError(-2, "Both input images must be CUDA uint8 tensors")
+        if left.device.index != self._device:
+            raise StereoBMError(-20, f"tensor on cuda:{left.device.index}, engine on device {self._device}")
+        left, right = left.contiguous(), right.contiguous()
+        shape = left.shape
+        n = 1 if left.dim() == 2 else shape[0]
+        h, w = shape[-2], shape[-1]
+        if disparity is None:
+            disparity = torch.empty(shape, dtype=torch.int16, device=left.device)
+        # the engine runs on its own stream: order it behind whatever produced the inputs
+        torch.cuda.current_stream(left.device).synchronize()
+        _check(self._L.sbm_compute_device(self._h, n, left.data_ptr(), right.data_ptr(), w, h, disparity.data_ptr(),
+                                          1 if sync else 0), self._h)
+        return disparity
+
+    def launch_raw(self, n, d_left, d_right, w, h, d_disp, sync=False):
+        """Thin call of sbm_compute_device on raw device addresses (used by bench.py's timed loop)."""
+        _check(self._L.sbm_compute_device(self._h, n, d_left, d_right, w, h, d_disp, 1 if sync else 0), self._h)
+
+    def synchronize(self):
+        _check(self._L.sbm_synchronize(self._h), self._h)
+
+    def stream(self):
+        return self._L.sbm_stream(self._h)
+
+    def set_profiling(self, on):
+        _check(self._L.sbm_set_profiling(self._h, 1 if on else 0), self._h)
+
+    def profile(self):
+        out = {}
+        for k in ("prefilter", "sad", "border", "lrcheck", "speckle", "total"):
+            v = ctypes.c_float()
+            _check(self._L.sbm_get_profile(self._h, k.encode(), ctypes.byref(v)), self._h)
+            out[k] = v.value
+        return out
+
+    def debug_fetch(self, which, n, h, w):
+        dt = {0: np.uint8, 1: np.uint8, 2: np.int32, 3: np.int16}[which]
+        a = np.empty((n, h, w), dt)
+        _check(self._L.sbm_debug_fetch(self._h, which, a.ctypes.data, a.nbytes), self._h)
+        return a
+
+
+def validate(params, width, height):
+    """Status code of cv::StereoBM::compute's parameter checks (0 = ok)."""
+    return load_library().sbm_params_validate(ctypes.byref(params), width, height)
