@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the stereo block-matching hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole path (prefilter -> SAD/WTA -> LR check -> speckle) over one batch of synthetic
+stereo pairs that is already resident in HBM. Workload at N=1: BASELINE.json configs[1] -- KITTI-shaped 1242x375 gray,
+ndisp=128, 15x15 SAD, with the post-filter chain of the reference call site (src/slam/src/core/main.cpp:206-212:
+texture 10, uniqueness 10, speckle 50/32, disp12MaxDiff 1) -- `--pairs` pairs per GPU per step (default 64 = the
+per-GPU share of configs[3]). Multi-GPU: one process per GPU (torch.distributed / RCCL), pair batches sharded with no
+data-path collective (weak scaling: per-GPU batch fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      dominant kernel (the SAD/WTA kernel): algorithmic HBM bytes per launch / its mean duration, measured
+                with HIP events on the engine's stream inside the timed region; `traffic` = HBM bytes per launch from
+                the committed rocprofv3 PMC run (profiles/), or null
+  cpu_baseline  the CPU oracle (a port, not OpenCV) timed on this host's cores on a bounded sample of the same batch
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+WORKLOADS = {
+    # name: (W, H, ndisp, block, default pairs per GPU)
+    "kitti": (1242, 375, 128, 15, 64),       # BASELINE configs[1] / configs[3] per-GPU share
+    "ref640": (640, 480, 64, 21, 64),        # configs[0] geometry with the reference's own window
+    "fhd": (1920, 1080, 256, 21, 16),        # configs[2] geometry
+    "uhd": (3840, 2160, 256, 21, 4),         # configs[4] geometry
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (0 = workload default)")
+    ap.add_argument("--block", type=int, default=0, help="override the SAD window")
+    ap.add_argument("--no-postfilter", action="store_true", help="SAD/WTA/texture/uniqueness only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--check", action="store_true", help="also verify pair 0 of rank 0 against the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import _pkg
+
+    pkg = _pkg.load()
+    from u96_slam_amd import synth
+
+    W, H, nd, wsz, pairs_default = WORKLOADS[args.workload]
+    if args.block:
+        wsz = args.block
+    B = args.pairs or pairs_default
+    post = not args.no_postfilter
+
+    # ---- synthetic shard for this rank (distinct pairs per rank), resident in HBM before timing starts ----------
+    uniq = min(B, 16)  # distinct pairs generated on the host; tiled up to B (keeps start-up short)
+    Lh, Rh = synth.make_batch(rank * B, uniq, W, H, nd)
+    reps = (B + uniq - 1) // uniq
+    Lh = np.concatenate([Lh] * reps)[:B]
+    Rh = np.concatenate([Rh] * reps)[:B]
+    dev = torch.device("cuda", local_rank)
+    dL, dR = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
+    dD = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+
+    bm = pkg.StereoBM.create(nd, wsz, device=local_rank)
+    bm.setPreFilterCap(31)
+    bm.setMinDisparity(0)
+    bm.setTextureThreshold(10)
+    bm.setUniquenessRatio(10)
+    if post:
+        bm.setSpeckleWindowSize(50)
+        bm.setSpeckleRange(32)
+        bm.setDisp12MaxDiff(1)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        bm.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    pl, pr, pd = dL.data_ptr(), dR.data_ptr(), dD.data_ptr()
+    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+        bm.launch_raw(B, pl, pr, W, H, pd)
+    sync_all()
+
+    bm.set_profiling(2)  # stage events recorded on the engine's stream, no host sync inside the timed region
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bm.launch_raw(B, pl, pr, W, H, pd)
+    bm.synchronize()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    prof = bm.profile()
+    bm.set_profiling(0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_pairs = world * B * args.steps
+    pixdisp_per_pair = W * H * nd
+    value = total_pairs * pixdisp_per_pair / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel ---------------------------------------------------------------------
+        stage = "sad" if prof["sad"] > prof["border"] else "border"
+        kms = prof[stage]
+        algo_bytes = 4.0 * W * H * B  # read L+R (2 B/px) + write int16 disparity (2 B/px) per pair
+        achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            try:
+                tj = json.loads(tfile.read_text())
+                key = f"{args.workload}_w{wsz}_b{B}"
+                if key in tj:
+                    traffic = tj[key]["bytes_per_launch"]
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "sad_fast_kernel" if stage == "sad" else "sad_generic_kernel",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                    "stage_ms": {k: round(v, 4) for k, v in prof.items()}}
+
+        # ---- CPU baseline (reported only) --------------------------------------------------------------------------
+        cpu = None
+        if not args.no_cpu_baseline:
+            import sbm_oracle
+
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = max(1, min(cores, sbm_oracle.max_threads()))
+            p = sbm_oracle.make_params(nd, wsz, 31, 0, 10, 10, 50 if post else 0, 32 if post else 0, 1 if post else -1)
+            t1 = time.perf_counter()
+            sbm_oracle.compute_batch(p, Lh[:1], Rh[:1], threads=1)
+            one = time.perf_counter() - t1
+            # about 20 s of single-core work in total, at least one pair per core
+            sample = args.cpu_sample or max(cores, min(8 * cores, int(round(20.0 / max(one, 1e-3)))))
+            idx = [i % B for i in range(sample)]
+            t1 = time.perf_counter()
+            ref = sbm_oracle.compute_batch(p, Lh[idx], Rh[idx], threads=cores)
+            cpu_s = time.perf_counter() - t1
+            cpu = {"value": round(sample * pixdisp_per_pair / cpu_s / 1e6, 2), "unit": "Mpix-disparities/s", "cores": cores,
+                   "kind": "port", "sample": f"{sample} pairs of the same {W}x{H} nd{nd} w{wsz} batch, {cpu_s:.2f} s wall, "
+                   "in-repo C restatement of cv::StereoBM (not OpenCV), OpenMP across pairs"}
+            if args.check:
+                got = dD[: min(sample, B)].cpu().numpy()
+                ok = all(np.array_equal(got[i], ref[i]) for i in range(min(sample, B)) if idx[i] == i)
+                cpu["bit_exact_vs_gpu"] = bool(ok)
+
+        out = {
+            "metric": "Mpix-disparities/s", "value": round(value, 2), "unit": "Mpix-disparities/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {W}x{H} gray, ndisp={nd}, {wsz}x{wsz} SAD, "
+                       + ("texture 10 / uniqueness 10 / disp12MaxDiff 1 / speckle 50,32" if post else "texture 10 / uniqueness 10, no LR/speckle"),
+                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, no data-path collective"},
+            "ms_per_pair": round(elapsed / (B * args.steps) * 1e3, 5),
+            "pairs_per_s": round(total_pairs / elapsed, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

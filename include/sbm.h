@@ -119,8 +119,12 @@ int sbm_synchronize(sbm_handle* h);
  * Copies n*height*width elements into host memory `dst`. */
 int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
 
-/* Per-kernel device time (ms, HIP events on the handle's stream) of the last sbm_compute_device call
- * made with profiling enabled. names: "prefilter","sad","border","lrcheck","speckle","total". */
+/* Per-stage device time in ms, measured with HIP events recorded on the handle's stream around each stage.
+ * enabled = 1: every sbm_compute_device call synchronises and sbm_get_profile returns that call's times;
+ * enabled = 2: events are recorded without synchronising (use inside a timed region) and sbm_get_profile
+ *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
+ * names: "prefilter", "sad" (fast SAD/WTA kernel), "border" (generic kernel on the clamped border columns, or on
+ * everything when the fast path is off), "lrcheck", "speckle", "total". */
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
 

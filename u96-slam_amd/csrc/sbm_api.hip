@@ -32,10 +32,13 @@ struct sbm_handle {
   // last launch (for sbm_debug_fetch)
   Geom last;
   bool have_last;
-  // profiling
+  // profiling: mode 1 = sync after every call and keep that call's stage times; mode 2 = record stage events of
+  // every call into a ring WITHOUT syncing (bench.py's timed region); sbm_get_profile then averages the ring.
   int profiling;
-  hipEvent_t ev[8];
-  bool ev_valid[8];
+  static constexpr int kRing = 64, kMarks = 6;
+  hipEvent_t ev[kRing][kMarks];
+  bool ev_ok;
+  unsigned calls;  // calls recorded since profiling was (re)enabled
   float ms_prefilter, ms_sad, ms_border, ms_lr, ms_speckle, ms_total;
 };
 
@@ -130,7 +133,9 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
     delete h;
     return SBM_ERR_NO_DEVICE;
   }
-  for (int i = 0; i < 8; i++) h->ev_valid[i] = hipEventCreate(&h->ev[i]) == hipSuccess;
+  h->ev_ok = true;
+  for (int r = 0; r < sbm_handle::kRing; r++)
+    for (int i = 0; i < sbm_handle::kMarks; i++) h->ev_ok &= hipEventCreate(&h->ev[r][i]) == hipSuccess;
   *out = h;
   return SBM_OK;
 }
@@ -141,8 +146,8 @@ void sbm_destroy(sbm_handle* h) {
   hipStreamSynchronize(h->stream);
   free_scratch(h);
   free_staging(h);
-  for (int i = 0; i < 8; i++)
-    if (h->ev_valid[i]) hipEventDestroy(h->ev[i]);
+  for (int r = 0; r < sbm_handle::kRing; r++)
+    for (int i = 0; i < sbm_handle::kMarks; i++) hipEventDestroy(h->ev[r][i]);
   hipStreamDestroy(h->stream);
   delete h;
 }
@@ -171,7 +176,9 @@ int sbm_synchronize(sbm_handle* h) {
 
 int sbm_set_profiling(sbm_handle* h, int enabled) {
   if (!h) return SBM_ERR_NULL;
-  h->profiling = enabled != 0;
+  h->profiling = enabled;
+  h->calls = 0;
+  h->ms_prefilter = h->ms_sad = h->ms_border = h->ms_lr = h->ms_speckle = h->ms_total = 0.f;
   return SBM_OK;
 }
 
@@ -216,7 +223,24 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
 }
 
 static inline void mark(sbm_handle* h, int i) {
-  if (h->profiling && h->ev_valid[i]) hipEventRecord(h->ev[i], h->stream);
+  if (h->profiling && h->ev_ok) hipEventRecord(h->ev[h->calls % sbm_handle::kRing][i], h->stream);
+}
+
+// average stage times over the recorded calls (at most the last kRing); the stream must be idle
+static void collect_profile(sbm_handle* h) {
+  const unsigned nrec = std::min<unsigned>(h->calls, sbm_handle::kRing);
+  float acc[5] = {0, 0, 0, 0, 0}, tot = 0.f;
+  for (unsigned r = 0; r < nrec; r++) {
+    for (int i = 0; i < 5; i++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[r][i], h->ev[r][i + 1]) == hipSuccess) acc[i] += ms;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[r][0], h->ev[r][5]) == hipSuccess) tot += ms;
+  }
+  const float inv = nrec ? 1.f / nrec : 0.f;
+  h->ms_prefilter = acc[0] * inv; h->ms_sad = acc[1] * inv; h->ms_border = acc[2] * inv; h->ms_lr = acc[3] * inv;
+  h->ms_speckle = acc[4] * inv; h->ms_total = tot * inv;
 }
 
 int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, int width, int height,
@@ -292,19 +316,16 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   if (speckle) HIPCHK(h, launch_speckle(out, h->labels, h->counts, g, p.speckle_window_size, p.speckle_range, h->stream));
   mark(h, 5);
   (void)npix;
-  if (sync || h->profiling) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->profiling) {
-      auto el = [&](int a, int b) { float ms = 0.f; if (h->ev_valid[a] && h->ev_valid[b]) hipEventElapsedTime(&ms, h->ev[a], h->ev[b]); return ms; };
-      h->ms_prefilter = el(0, 1); h->ms_sad = el(1, 2); h->ms_border = el(2, 3); h->ms_lr = el(3, 4);
-      h->ms_speckle = el(4, 5); h->ms_total = el(0, 5);
-    }
-  }
+  if (h->profiling) h->calls++;
+  if (sync || h->profiling == 1) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
 }
 
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms) {
   if (!h || !name || !ms) return SBM_ERR_NULL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->profiling && h->ev_ok) collect_profile(h);
   if (!strcmp(name, "prefilter")) *ms = h->ms_prefilter;
   else if (!strcmp(name, "sad")) *ms = h->ms_sad;
   else if (!strcmp(name, "border")) *ms = h->ms_border;
