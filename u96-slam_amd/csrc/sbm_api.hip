@@ -204,7 +204,7 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
   if (!fits) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     free_scratch(h);
-    const size_t npix = (size_t)n * W * H, pfbytes = (size_t)n * pitch * H + 64;
+    const size_t npix = (size_t)n * W * H, pfbytes = (size_t)n * pitch * H + 4096;
     HIPCHK(h, hipMalloc((void**)&h->pf_l, pfbytes));
     HIPCHK(h, hipMalloc((void**)&h->pf_r, pfbytes));
     HIPCHK(h, hipMalloc((void**)&h->disp_pre, npix * sizeof(int16_t)));

@@ -1,9 +1,326 @@
-// sbm_sad_fast.hip -- fast SAD/WTA kernel (placeholder until the mqsad kernel lands).
+// sbm_sad_fast.hip -- the hot kernel: windowed SAD over the disparity range + WTA + texture + uniqueness +
+// sub-pixel, for the interior (unclamped) columns.  gfx950 / CDNA4 only.
+//
+// Device counterpart of findStereoCorrespondenceBM (OpenCV calib3d stereobm.cpp) reached from
+// src/slam/src/core/main.cpp:215.  In-tree hardware twins: src/dvp/rtl/bm_calc_sad.v:391-605 (34-lane abs-diff,
+// vertical running sums, horizontal running SAD), bm_calc_det.v:124-426 (WTA tree), bm_calc_frac.v (sub-pixel).
+//
+// Mapping (one 64-lane wavefront = one workgroup; no barriers):
+//   lane      = one image column c (64 consecutive columns per wavefront), marching down a row segment
+//   registers = V[d]: for every disparity the sum over the w window rows of the 3-column SAD
+//               H3(c,y,d) = sum_{i<3} |Lp[y][c+i] - Rp[y][c+i-D]|, packed 4 x u16 per VGPR pair.
+//               One v_mqsad_pk_u16_u8 produces H3 for 4 consecutive disparities AND accumulates (pattern = 3 left
+//               bytes + a zero byte, which the instruction masks; sliding 8-byte window = right bytes).
+//               Entering row: V = mqsad(R, L, V).  Leaving row: V -= mqsad(R, L, 0).
+//   LDS       = the right row piece of the wavefront, expanded 16x (slot p holds bytes p..p+15) so that every lane's
+//               16-byte-aligned ds_read_b128 stream starts at its own byte offset; conflict-free (lane stride 16 B).
+//   wave ops  = horizontal window: S(c + w/2) = sum_k V(c + 3k), k < w/3, by log-step ds_bpermute adds
+//               (w = 15: T = V + V<<3 lanes, U = T + T<<6, S = U + V<<12); lanes whose partners fall outside the
+//               wavefront (the last w-3) produce nothing and are recomputed by the next strip.
+//   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan),
+//               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree.
+// Envelope (checked on the host, everything else takes the generic kernel): w in {9,15,21,27}, nd <= 128,
+// w*w*2*cap <= 65534 (16-bit sums), 2*(maxS*uniq/100+1) < 65535, valid-ROI rows inside [w/2, H-w/2).
+#include <algorithm>
+
 #include "sbm_common.h"
+
 namespace sbm {
-bool sad_fast_supported(const Geom&) { return false; }
-hipError_t launch_sad_fast(const uint8_t*, const uint8_t*, int16_t*, int32_t*, const Geom&, int* xa, int* xb, hipStream_t) {
-  *xa = *xb = 0;
-  return hipSuccess;
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+struct FastArgs {
+  const uint8_t* pf_l;
+  const uint8_t* pf_r;
+  int16_t* disp;
+  int32_t* cost;
+  int W, H, pitch, padl, plane;
+  int nd, mindisp, lofs, rofs, tex, uniq, filtered, capb;
+  int row0, row1, seg;       // rows [row0,row1) in segments of `seg`
+  int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
+};
+
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
 }
+__device__ __forceinline__ u32 load_u32_ua(const uint8_t* p) {
+  u32 v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ u32 bperm(int byte_addr, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v); }
+__device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b) {
+  u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+  return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_add_sat(u32 a, u32 b) {
+  u16x2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+  return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(a, min(b, c)); }
+
+// horizontal window sum across lanes of a packed-u16 (or plain u32) register; result for centre c + w/2 lands in lane c
+template <int NTERM>
+__device__ __forceinline__ u32 hsum(u32 r, int a3, int a6, int a12, int a18, int a24) {
+  if constexpr (NTERM == 3) {
+    u32 t = r + bperm(a3, r);
+    return t + bperm(a6, r);
+  } else if constexpr (NTERM == 5) {
+    u32 t = r + bperm(a3, r);
+    u32 u = t + bperm(a6, t);
+    return u + bperm(a12, r);
+  } else if constexpr (NTERM == 7) {
+    u32 t = r + bperm(a3, r);
+    u32 u = t + bperm(a6, t);
+    u32 x = u + bperm(a12, t);
+    return x + bperm(a18, r);
+  } else {  // 9
+    u32 t = r + bperm(a3, r);
+    u32 u = t + bperm(a6, t);
+    u32 y = u + bperm(a12, u);
+    return y + bperm(a24, r);
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // NSLOT 16-byte slots
+
+template <int ND, int NTERM, bool EXACT_ND>
+__global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
+  constexpr int NQ = ND / 4;            // disparity quads (one u64 accumulator each)
+  constexpr int NR = ND / 2;            // packed pair registers
+  constexpr int NRD = ND / 16 + 1;      // ds_read_b128 per alignment
+  constexpr int NSLOT = ((64 + 4 + 16 * (NRD - 1) + 1) + 63) / 64 * 64;
+  constexpr int NIT = NSLOT / 64;
+  constexpr int WSZ = 3 * NTERM, W2 = WSZ / 2;
+  constexpr int NV = 64 - (WSZ - 3);    // lanes that produce an output
+
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x * NV + lane;                 // this lane's column (relative to lofs): V covers c..c+2
+  const int xc = c + W2;                                // centre column this lane produces
+  const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
+  const int ys = a.row0 + blockIdx.y * a.seg;
+  const int ye = min(ys + a.seg, a.row1);
+  const int pair = blockIdx.z;
+  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;               // left bytes of this lane
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + blockIdx.x * NV; // right piece of the wave
+  const u32 capw = (u32)a.capb * 0x01010101u;
+  const int a3 = ((lane + 3) & 63) << 2, a6 = ((lane + 6) & 63) << 2, a12 = ((lane + 12) & 63) << 2,
+            a18 = ((lane + 18) & 63) << 2, a24 = ((lane + 24) & 63) << 2;
+
+  u64 V[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) V[q] = 0;
+  u32 Vt = 0;  // texture: window-row sum of the 3-column |L - cap|
+
+  // Stage one right row piece into the expanded LDS layout, then feed it to mqsad.  SUB = leaving row.
+  auto row_step = [&](int y, bool sub) {
+    const uint8_t* rrow = pr + (size_t)y * a.pitch;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int slot = it * 64 + lane;
+      fast_lds[slot] = load_u128_unaligned(rrow + slot);
+    }
+    const u32 lraw = load_u32_ua(pl + (size_t)y * a.pitch);
+    const u32 pat = lraw & 0x00ffffffu;  // byte 3 = 0 -> masked by mqsad
+    const u32 tv = __builtin_amdgcn_sad_u8(pat | ((u32)a.capb << 24), capw, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint4 ra[NRD], rb[NRD];
+#pragma unroll
+    for (int m = 0; m < NRD; m++) {
+      ra[m] = fast_lds[lane + 16 * m];
+      rb[m] = fast_lds[lane + 4 + 16 * m];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      // window dwords (q, q+1): even q from ra, odd q from rb (= the same bytes shifted by one dword)
+      u32 lo, hi;
+      if ((q & 1) == 0) {
+        const uint4 v = ra[q >> 2];
+        lo = (q & 2) ? v.z : v.x;
+        hi = (q & 2) ? v.w : v.y;
+      } else {
+        const uint4 v = rb[(q - 1) >> 2];
+        lo = ((q - 1) & 2) ? v.z : v.x;
+        hi = ((q - 1) & 2) ? v.w : v.y;
+      }
+      const u64 win = ((u64)hi << 32) | lo;
+      if (!sub) {
+        V[q] = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, V[q]);
+      } else {
+        const u64 t = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull);
+        const u32 vlo = (u32)V[q] - (u32)t, vhi = (u32)(V[q] >> 32) - (u32)(t >> 32);  // no u16 lane borrows
+        V[q] = ((u64)vhi << 32) | vlo;
+      }
+    }
+    Vt = sub ? Vt - tv : Vt + tv;
+  };
+
+  // prime: rows ys-W2 .. ys+W2-1
+  for (int yy = ys - W2; yy < ys + W2; yy++) row_step(yy, false);
+
+  const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
+  for (int y = ys; y < ye; y++) {
+    row_step(y + W2, false);
+
+    // ---- horizontal window across lanes ------------------------------------------------------------------
+    u32 S[NR];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      S[2 * q] = hsum<NTERM>((u32)V[q], a3, a6, a12, a18, a24);
+      S[2 * q + 1] = hsum<NTERM>((u32)(V[q] >> 32), a3, a6, a12, a18, a24);
+    }
+    const int tsum = (int)hsum<NTERM>(Vt, a3, a6, a12, a18, a24);
+    if constexpr (!EXACT_ND) {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        if (2 * j >= a.nd) S[j] = 0xffffffffu;
+    }
+
+    // ---- WTA: first index attaining the minimum ------------------------------------------------------------
+    u32 best = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const u32 klo = (S[j] << 16) | (u32)(2 * j);
+      const u32 khi = (S[j] & 0xffff0000u) | (u32)(2 * j + 1);
+      best = umin3(best, klo, khi);
+    }
+    const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
+    bool ok = tsum >= a.tex;
+
+    // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
+    const int in_ = mind > 0 ? mind - 1 : 1;
+    const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
+    u32 X[NQ];
+    {
+      const u32 an = (u32)(in_ & 3) * 2, ap = (u32)(ip_ & 3) * 2;
+      const u32 sel = an | ((an + 1) << 8) | (ap << 16) | ((ap + 1) << 24);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
+    }
+    {
+      int qn = in_ >> 2, qp = ip_ >> 2;
+#pragma unroll
+      for (int n = NQ; n > 1; n >>= 1) {
+        // low half follows bit0 of qn, high half bit0 of qp; src0 = odd entry (bytes 4..7), src1 = even (0..3)
+        const u32 sel = ((qn & 1) ? 0x0504u : 0x0100u) | ((qp & 1) ? 0x07060000u : 0x03020000u);
+#pragma unroll
+        for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
+        qn >>= 1;
+        qp >>= 1;
+      }
+    }
+    const int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
+
+    // ---- uniqueness: any d outside [mind-1, mind+1] with S[d] <= thresh rejects --------------------------------
+    if (a.uniq > 0) {
+      const int thresh = minsad + (minsad * a.uniq / 100);
+      const u32 T = (u32)min(thresh + 1, 65535);
+      const u32 T2 = T | (T << 16);
+      u32 acc = 0;
+#pragma unroll
+      for (int j = 0; j < NR; j++) acc = pk_add_sat(acc, pk_sub_sat(T2, S[j]));
+      // expected deficits of the three neighbourhood entries, per 16-bit half (even / odd buffer index)
+      const u32 dm = T - (u32)minsad;                                   // >= 1
+      const u32 dn = (mind > 0 && (u32)nn < T) ? T - (u32)nn : 0u;       // S[mind-1] exists
+      const u32 dp = (mind < a.nd - 1 && (u32)pp < T) ? T - (u32)pp : 0u; // S[mind+1] exists
+      const u32 e_same = dm, e_other = dn + dp;                          // mind's parity half / the other half
+      const u32 exp_lo = (mind & 1) ? e_other : e_same, exp_hi = (mind & 1) ? e_same : e_other;
+      ok = ok && (acc & 0xffffu) == exp_lo && (acc >> 16) == exp_hi;
+    }
+
+    if (produces) {
+      int out = a.filtered;
+      if (ok) {
+        const int ad = pp > nn ? pp - nn : nn - pp;
+        const int den = pp + nn - 2 * minsad + ad;
+        int frac = 0;
+        if (den != 0) {
+          const u32 num = (u32)ad << 8;
+          u32 qv = (u32)((float)num / (float)den);      // |p-n|*256 < 2^24: estimate is within 1 of the quotient
+          while ((u64)qv * (u32)den > num) qv--;
+          while ((u64)(qv + 1) * (u32)den <= num) qv++;
+          frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
+        }
+        out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
+        if (a.cost) a.cost[obase + (size_t)y * a.W] = minsad;
+      }
+      a.disp[obase + (size_t)y * a.W] = (int16_t)out;
+    }
+
+    if (y + 1 < ye) row_step(y - W2, true);
+  }
+}
+
+bool sad_fast_supported(const Geom& g) {
+  if (g.wsz != 9 && g.wsz != 15 && g.wsz != 21 && g.wsz != 27) return false;
+  if (g.nd > 128) return false;
+  const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
+  if (maxs > 65534) return false;
+  if (2 * (maxs * g.uniq / 100 + 1) >= 65535) return false;
+  if (g.row0 < g.w2 || g.row1 > g.H - g.w2 || g.row1 <= g.row0) return false;
+  const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);  // last unclamped window column
+  if (xhi - g.w2 + 1 <= g.w2) return false;
+  return true;
+}
+
+template <int ND, int NTERM>
+static hipError_t launch_t(const FastArgs& a, dim3 grid, bool exact, hipStream_t s) {
+  constexpr int NRD = ND / 16 + 1;
+  constexpr int NSLOT = ((64 + 4 + 16 * (NRD - 1) + 1) + 63) / 64 * 64;
+  const size_t lds = (size_t)NSLOT * 16;
+  if (exact)
+    hipLaunchKernelGGL((sad_fast_kernel<ND, NTERM, true>), grid, dim3(64), lds, s, a);
+  else
+    hipLaunchKernelGGL((sad_fast_kernel<ND, NTERM, false>), grid, dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int NTERM>
+static hipError_t launch_nd(const FastArgs& a, dim3 grid, hipStream_t s) {
+  if (a.nd <= 32) return launch_t<32, NTERM>(a, grid, a.nd == 32, s);
+  if (a.nd <= 64) return launch_t<64, NTERM>(a, grid, a.nd == 64, s);
+  return launch_t<128, NTERM>(a, grid, a.nd == 128, s);
+}
+
+hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
+                           int* xa, int* xb, hipStream_t s) {
+  *xa = *xb = 0;
+  if (!sad_fast_supported(g)) return hipSuccess;
+  FastArgs a;
+  a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? cost : nullptr;
+  a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
+  a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex; a.uniq = g.uniq;
+  a.filtered = g.filtered; a.capb = g.cap + kPfBias;
+  a.row0 = g.row0; a.row1 = g.row1;
+  const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
+  a.xc0 = g.w2; a.xc1 = xhi - g.w2 + 1;
+  const int nterm = g.wsz / 3;
+  const int nv = 64 - (g.wsz - 3);
+  const int strips = (a.xc1 - a.xc0 + nv - 1) / nv;
+  const int rows = g.row1 - g.row0;
+  // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
+  // segment at ~1/3 of a full row's cost) below ~10 %
+  int nseg = 1;
+  const long target = 8192;
+  while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
+  a.seg = (rows + nseg - 1) / nseg;
+  nseg = (rows + a.seg - 1) / a.seg;
+  dim3 grid(strips, nseg, g.n);
+  hipError_t e;
+  switch (nterm) {
+    case 3: e = launch_nd<3>(a, grid, s); break;
+    case 5: e = launch_nd<5>(a, grid, s); break;
+    case 7: e = launch_nd<7>(a, grid, s); break;
+    default: e = launch_nd<9>(a, grid, s); break;
+  }
+  *xa = a.xc0; *xb = a.xc1;
+  return e;
+}
+
 }  // namespace sbm
