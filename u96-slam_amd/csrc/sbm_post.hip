@@ -92,9 +92,16 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 
 // ---------------------------------------------------------------------------------------------------------
 // Speckle filter.  cv's raster-order flood fill yields plain 4-connected components of the relation
-// "both != newVal and |a-b| <= maxDiff" (order-independent), so it is computed here with
-// a lock-free union-find: init -> merge right/down edges (atomicMin hooks) -> flatten + count -> threshold.
-// Labels are pixel indices within the pair's own plane.
+// "both != newVal and |a-b| <= maxDiff" (order-independent), so it is computed here as
+// run-based union-find:
+//   1. runs    one wavefront per image row: every pixel gets the index of the first pixel of its horizontal run
+//              (ballot + count-leading-zeros, carry across 64-pixel chunks); run heads are their own parents.
+//   2. merge   one thread per pixel: union the runs of vertically connected pixels, skipping contacts that the
+//              pixel to the left already made (same two runs) -- so the number of atomics ~ number of run contacts.
+//   3. count   root of every pixel; a wavefront adds each equal-root lane segment with ONE atomic, and stops
+//              adding to a component once it is known to exceed maxSpeckleSize (kills contention on large regions).
+//   4. apply   components with count <= maxSpeckleSize become newVal.
+// labels doubles as the parent array (indices within the pair's plane, -1 = invalid pixel).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int uf_find(const int* L, int i) {
   int r = i;
@@ -117,45 +124,81 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   }
 }
 
-__global__ void __launch_bounds__(256) speckle_init_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
-                                                            int* __restrict__ counts, int npix, int newval) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= npix) return;
-  const size_t o = (size_t)blockIdx.y * npix + i;
-  labels[o] = disp[o] != newval ? i : -1;
-  counts[o] = 0;
+// grid: (ceil(H/4), n), block 256 = 4 wavefronts = 4 rows
+__global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
+                                                            int* __restrict__ counts, int W, int H, int newval,
+                                                            int maxdiff) {
+  const int lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (y >= H) return;
+  const size_t po = (size_t)blockIdx.y * W * H + (size_t)y * W;
+  const int16_t* d = disp + po;
+  int* L = labels + po;
+  int* C = counts + po;
+  int carry = -1;         // run start of the pixel just left of this chunk (only used when connected to it)
+  int prev_last = newval; // value of the pixel just left of this chunk
+  for (int cb = 0; cb < W; cb += 64) {
+    const int x = cb + lane;
+    const bool in = x < W;
+    const int v = in ? (int)d[x] : newval;
+    int pv = __shfl_up(v, 1, 64);
+    if (lane == 0) pv = prev_last;
+    const bool valid = v != newval;
+    const bool joined = valid && pv != newval && abs(v - pv) <= maxdiff;  // connected to the left neighbour
+    const bool head = valid && !joined;
+    const unsigned long long m = __ballot(head) & ((2ull << lane) - 1ull);
+    const int start = m ? cb + (63 - __clzll((long long)m)) : carry;
+    if (in) {
+      L[x] = valid ? y * W + start : -1;
+      C[x] = 0;
+    }
+    carry = __shfl(valid ? start : -1, 63, 64);
+    prev_last = __shfl(v, 63, 64);
+  }
 }
 
 __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
                                                              int W, int H, int newval, int maxdiff) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int npix = W * H;
-  if (i >= npix) return;
+  if (i >= npix - W) return;  // last row has no row below
   const size_t po = (size_t)blockIdx.y * npix;
   const int16_t* d = disp + po;
   int* L = labels + po;
-  const int v = d[i];
-  if (v == newval) return;
-  const int x = i % W, y = i / W;
-  if (x + 1 < W) {
-    const int u = d[i + 1];
-    if (u != newval && abs(v - u) <= maxdiff) uf_union(L, i, i + 1);
+  const int v = d[i], u = d[i + W];
+  if (v == newval || u == newval || abs(v - u) > maxdiff) return;
+  const int la = L[i], lb = L[i + W];
+  const int x = i % W;
+  if (x > 0) {
+    const int v1 = d[i - 1], u1 = d[i - 1 + W];
+    if (v1 != newval && u1 != newval && abs(v1 - u1) <= maxdiff && L[i - 1] == la && L[i - 1 + W] == lb) return;
   }
-  if (y + 1 < H) {
-    const int u = d[i + W];
-    if (u != newval && abs(v - u) <= maxdiff) uf_union(L, i, i + W);
-  }
+  uf_union(L, la, lb);
 }
 
-__global__ void __launch_bounds__(256) speckle_count_kernel(int* __restrict__ labels, int* __restrict__ counts, int npix) {
+__global__ void __launch_bounds__(256) speckle_count_kernel(int* __restrict__ labels, int* __restrict__ counts, int npix,
+                                                             int maxsize) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= npix) return;
+  const int lane = threadIdx.x & 63;
   const size_t po = (size_t)blockIdx.y * npix;
   int* L = labels + po;
-  if (L[i] < 0) return;
-  const int r = uf_find(L, i);
-  L[i] = r;  // roots are final (merge kernel finished), so this is a pure shortcut
-  atomicAdd(counts + po + r, 1);
+  int r = -1;
+  if (i < npix) {
+    const int l = L[i];
+    if (l >= 0) {
+      r = uf_find(L, l);
+      L[i] = r;  // roots are final (merge finished): pure shortcut for the apply pass
+    }
+  }
+  int pr = __shfl_up(r, 1, 64);
+  const bool seg = lane == 0 || pr != r;
+  const unsigned long long m = __ballot(seg);
+  if (seg && r >= 0) {
+    const unsigned long long above = lane == 63 ? 0ull : (m >> (lane + 1));
+    const int len = above ? __ffsll((long long)above) : 64 - lane;
+    int* c = counts + po + r;
+    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(c, len);
+  }
 }
 
 __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict__ disp, const int* __restrict__ labels,
@@ -172,9 +215,10 @@ hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const
                           hipStream_t s) {
   const int npix = g.W * g.H;
   dim3 grid((npix + 255) / 256, g.n);
-  hipLaunchKernelGGL(speckle_init_kernel, grid, dim3(256), 0, s, disp, labels, counts, npix, g.filtered);
+  hipLaunchKernelGGL(speckle_runs_kernel, dim3((g.H + 3) / 4, g.n), dim3(256), 0, s, disp, labels, counts, g.W, g.H,
+                     g.filtered, max_diff);
   hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
-  hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, labels, counts, npix);
+  hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, labels, counts, npix, max_size);
   hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, npix, g.filtered, max_size);
   return hipGetLastError();
 }
