@@ -107,6 +107,18 @@ SMALL_CASES = [
     (61, 131, dict(num_disparities=48, block_size=13, texture_threshold=3, uniqueness_ratio=20, disp12_max_diff=1)),
     (50, 100, dict(num_disparities=16, block_size=33, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
     (60, 120, dict(num_disparities=32, block_size=9, roi1=(10, 5, 100, 50), roi2=(4, 2, 110, 55), disp12_max_diff=1)),
+    # fast-kernel envelope corners: disparity counts below the template size, minDisparity != 0, cap 63, windows 9..27
+    (50, 150, dict(num_disparities=16, block_size=15, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (47, 160, dict(num_disparities=48, block_size=9, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1,
+                   speckle_window_size=30, speckle_range=16)),
+    (70, 260, dict(num_disparities=96, block_size=21, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (80, 300, dict(num_disparities=112, block_size=27, texture_threshold=20, uniqueness_ratio=5, disp12_max_diff=2)),
+    (55, 140, dict(num_disparities=32, block_size=9, min_disparity=-8, texture_threshold=5, uniqueness_ratio=10, disp12_max_diff=1)),
+    (55, 140, dict(num_disparities=32, block_size=15, min_disparity=4, texture_threshold=5, uniqueness_ratio=10, disp12_max_diff=1)),
+    (64, 180, dict(num_disparities=64, block_size=21, prefilter_cap=63, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (64, 180, dict(num_disparities=64, block_size=15, prefilter_cap=5, texture_threshold=0, uniqueness_ratio=60, disp12_max_diff=1)),
+    (64, 180, dict(num_disparities=64, block_size=15, texture_threshold=0, uniqueness_ratio=0, disp12_max_diff=0)),
+    (40, 400, dict(num_disparities=128, block_size=9, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
 ]
 
 
@@ -154,6 +166,22 @@ def test_full_hd_nd256_bit_exact(torch_cuda, pkg, oracle):
               speckle_window_size=50, speckle_range=32, disp12_max_diff=1)
     eng, ref = run_engine(pkg, oracle, kw, L, R, stages=False)
     assert_stages_equal(eng, ref, kw)
+
+
+@pytest.mark.parametrize("levels,wsz,nd", [(2, 15, 64), (3, 9, 32), (4, 21, 128), (2, 27, 64)])
+def test_tie_heavy_images(torch_cuda, pkg, oracle, levels, wsz, nd):
+    """Few grey levels and no texture/uniqueness rejection: SAD ties everywhere, so the 'first index wins' rule, the
+    mirrored sub-pixel neighbours at d = 0 / nd-1 and the uniqueness bookkeeping are all exercised."""
+    rng = np.random.default_rng(levels * 100 + wsz)
+    h, w = 3 * wsz + 11, nd + 4 * wsz + 37
+    L = (rng.integers(0, levels, (h, w)) * (255 // max(levels - 1, 1))).astype(np.uint8)
+    L = np.repeat(np.repeat(L[::4, ::4], 4, 0), 4, 1)[:h, :w].copy()      # blocky: large exactly-equal regions
+    R = np.roll(L, -3, axis=1)
+    for uniq, tex in ((0, 0), (10, 0), (0, 10)):
+        kw = dict(num_disparities=nd, block_size=wsz, texture_threshold=tex, uniqueness_ratio=uniq, disp12_max_diff=1,
+                  speckle_window_size=10, speckle_range=8)
+        eng, ref = run_engine(pkg, oracle, kw, L, R)
+        assert_stages_equal(eng, ref, kw)
 
 
 def test_device_entry_point_matches_host_entry_point(torch_cuda, pkg, oracle):

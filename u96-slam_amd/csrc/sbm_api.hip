@@ -304,8 +304,12 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
     if (fb <= fa) {
       HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
     } else if (borders_visible) {
-      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, fa, h->stream));
-      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fb, g.xend, h->stream));
+      if (fa == g.w2 && g.xend - fb == g.w2) {
+        HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream));
+      } else {
+        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, fa, h->stream));
+        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fb, g.xend, h->stream));
+      }
     }
   } else {
     mark(h, 2);

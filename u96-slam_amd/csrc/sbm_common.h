@@ -42,6 +42,11 @@ bool sad_fast_supported(const Geom& g);
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                            int* xa, int* xb, hipStream_t s);
 
+// Border columns next to the fast range: [0,xa) and [xb,xend), w/2 columns each, clamped windows, sliding sums over
+// "virtual columns" (see sbm_sad_border.hip). Same envelope as the fast kernel.
+hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
+                             int xa, int xb, hipStream_t s);
+
 // Left-right consistency (cv validateDisparity) + invalid rows/columns fill. Reads disp_pre/cost, writes disp_out.
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
                           int disp12_max_diff, hipStream_t s);
