@@ -186,8 +186,11 @@ __global__ void __launch_bounds__(256) speckle_count_kernel(int* __restrict__ la
   if (i < npix) {
     const int l = L[i];
     if (l >= 0) {
-      r = uf_find(L, l);
-      L[i] = r;  // roots are final (merge finished): pure shortcut for the apply pass
+      // the merge kernel has finished: parents are final, so plain (L1-cacheable) loads are safe here; concurrent
+      // shortcut stores below only ever write a node's final root
+      r = l;
+      for (int p2 = L[r]; p2 != r; p2 = L[r]) r = p2;
+      L[i] = r;
     }
   }
   int pr = __shfl_up(r, 1, 64);

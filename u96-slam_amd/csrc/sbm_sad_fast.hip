@@ -92,8 +92,8 @@ template <int ND, int NTERM, bool EXACT_ND>
 __global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
   constexpr int NQ = ND / 4;            // disparity quads (one u64 accumulator each)
   constexpr int NR = ND / 2;            // packed pair registers
-  constexpr int NRD = ND / 16 + 1;      // ds_read_b128 per alignment
-  constexpr int NSLOT = ((64 + 4 + 16 * (NRD - 1) + 1) + 63) / 64 * 64;
+  constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
+  constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   constexpr int NIT = NSLOT / 64;
   constexpr int WSZ = 3 * NTERM, W2 = WSZ / 2;
   constexpr int NV = 64 - (WSZ - 3);    // lanes that produce an output
@@ -111,149 +111,198 @@ __global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
   const int a3 = ((lane + 3) & 63) << 2, a6 = ((lane + 6) & 63) << 2, a12 = ((lane + 12) & 63) << 2,
             a18 = ((lane + 18) & 63) << 2, a24 = ((lane + 24) & 63) << 2;
 
-  u64 V[NQ];
+  // packed 4 x u16 per quad (low dword = indices 4q,4q+1, high dword = 4q+2,4q+3).  Two arrays in ping-pong:
+  // v_mqsad_pk_u16_u8 may not write a register it reads, so an entering row maps VA -> VB through the
+  // instruction's free accumulate and the leaving row maps VB -> VA with plain subtractions.
+  uint2 VA[NQ];
+  u64 VB[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; q++) V[q] = 0;
+  for (int q = 0; q < NQ; q++) VA[q] = make_uint2(0u, 0u);
   u32 Vt = 0;  // texture: window-row sum of the 3-column |L - cap|
 
-  // Stage one right row piece into the expanded LDS layout, then feed it to mqsad.  SUB = leaving row.
-  auto row_step = [&](int y, bool sub) {
+  // One row of one image contributes in three phases, split so that global-load latency overlaps compute:
+  //   fetch  : global -> registers (this wavefront's right row piece + this lane's left bytes)
+  //   expand : registers -> LDS in the 16x expanded layout
+  //   apply  : LDS -> mqsad -> V (add for an entering row, subtract for a leaving row)
+  struct RowRegs { uint4 r[NIT]; u32 l; };
+  auto fetch = [&](int y) {
+    RowRegs g;
     const uint8_t* rrow = pr + (size_t)y * a.pitch;
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int slot = it * 64 + lane;
-      fast_lds[slot] = load_u128_unaligned(rrow + slot);
-    }
-    const u32 lraw = load_u32_ua(pl + (size_t)y * a.pitch);
-    const u32 pat = lraw & 0x00ffffffu;  // byte 3 = 0 -> masked by mqsad
+    for (int it = 0; it < NIT; it++) g.r[it] = load_u128_unaligned(rrow + it * 64 + lane);
+    g.l = load_u32_ua(pl + (size_t)y * a.pitch);
+    return g;
+  };
+  // mode 0: VB = VA + row (enter)   mode 1: VA = VB - row (leave)   mode 2: VA = VB + row (second half of a prime pair)
+  auto apply = [&](const RowRegs& g, const int mode) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) fast_lds[it * 64 + lane] = g.r[it];
+    const u32 pat = g.l & 0x00ffffffu;  // byte 3 = 0 -> masked by mqsad
     const u32 tv = __builtin_amdgcn_sad_u8(pat | ((u32)a.capb << 24), capw, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint4 ra[NRD], rb[NRD];
+    // 16 quads (64 disparities) at a time: 5 + 5 ds_read_b128 cover their 17 window dwords in both alignments.
+    // Chunking keeps the staged right bytes at 40 VGPRs instead of 72.
 #pragma unroll
-    for (int m = 0; m < NRD; m++) {
-      ra[m] = fast_lds[lane + 16 * m];
-      rb[m] = fast_lds[lane + 4 + 16 * m];
+    for (int q0 = 0; q0 < NQ; q0 += 16) {
+      constexpr int NM = 5;
+      uint4 ra[NM], rb[NM];
+#pragma unroll
+      for (int m = 0; m < NM; m++) {
+        ra[m] = fast_lds[lane + 16 * (q0 / 4 + m)];
+        rb[m] = fast_lds[lane + 4 + 16 * (q0 / 4 + m)];
+      }
+#pragma unroll
+      for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
+        const int q = q0 + qq;
+        // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
+        u32 lo, hi;
+        if ((qq & 1) == 0) {
+          const uint4 v = ra[qq >> 2];
+          lo = (qq & 2) ? v.z : v.x;
+          hi = (qq & 2) ? v.w : v.y;
+        } else {
+          const uint4 v = rb[(qq - 1) >> 2];
+          lo = ((qq - 1) & 2) ? v.z : v.x;
+          hi = ((qq - 1) & 2) ? v.w : v.y;
+        }
+        const u64 win = ((u64)hi << 32) | lo;
+        if (mode == 0) {
+          VB[q] = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, __builtin_bit_cast(u64, VA[q]));
+        } else if (mode == 2) {
+          VA[q] = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, VB[q]));
+        } else {
+          const u64 t = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull);
+          const uint2 vb = __builtin_bit_cast(uint2, VB[q]), tt = __builtin_bit_cast(uint2, t);
+          VA[q].x = vb.x - tt.x;                                // no u16 lane borrows: every partial sum is exact
+          VA[q].y = vb.y - tt.y;
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      // window dwords (q, q+1): even q from ra, odd q from rb (= the same bytes shifted by one dword)
-      u32 lo, hi;
-      if ((q & 1) == 0) {
-        const uint4 v = ra[q >> 2];
-        lo = (q & 2) ? v.z : v.x;
-        hi = (q & 2) ? v.w : v.y;
-      } else {
-        const uint4 v = rb[(q - 1) >> 2];
-        lo = ((q - 1) & 2) ? v.z : v.x;
-        hi = ((q - 1) & 2) ? v.w : v.y;
-      }
-      const u64 win = ((u64)hi << 32) | lo;
-      if (!sub) {
-        V[q] = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, V[q]);
-      } else {
-        const u64 t = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull);
-        const u32 vlo = (u32)V[q] - (u32)t, vhi = (u32)(V[q] >> 32) - (u32)(t >> 32);  // no u16 lane borrows
-        V[q] = ((u64)vhi << 32) | vlo;
-      }
-    }
-    Vt = sub ? Vt - tv : Vt + tv;
+    Vt = mode == 1 ? Vt - tv : Vt + tv;
   };
 
-  // prime: rows ys-W2 .. ys+W2-1
-  for (int yy = ys - W2; yy < ys + W2; yy++) row_step(yy, false);
-
-  const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
-  for (int y = ys; y < ye; y++) {
-    row_step(y + W2, false);
-
-    // ---- horizontal window across lanes ------------------------------------------------------------------
-    u32 S[NR];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      S[2 * q] = hsum<NTERM>((u32)V[q], a3, a6, a12, a18, a24);
-      S[2 * q + 1] = hsum<NTERM>((u32)(V[q] >> 32), a3, a6, a12, a18, a24);
+  // prime: rows ys-W2 .. ys+W2-1, then the entering row of the first output row is fetched ahead
+  {
+    RowRegs g = fetch(ys - W2);
+    for (int yy = ys - W2; yy < ys + W2; yy += 2) {   // 2*W2 rows: an even count, processed in VA->VB->VA pairs
+      RowRegs n1 = fetch(yy + 1);
+      apply(g, 0);
+      RowRegs n2 = fetch(yy + 2);
+      apply(n1, 2);
+      g = n2;
     }
-    const int tsum = (int)hsum<NTERM>(Vt, a3, a6, a12, a18, a24);
-    if constexpr (!EXACT_ND) {
-#pragma unroll
-      for (int j = 0; j < NR; j++)
-        if (2 * j >= a.nd) S[j] = 0xffffffffu;
-    }
+    // g now holds row ys+W2
+    const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
+    for (int y = ys; y < ye; y++) {
+      apply(g, 0);
 
-    // ---- WTA: first index attaining the minimum ------------------------------------------------------------
-    u32 best = 0xffffffffu;
+      // ---- horizontal window across lanes ------------------------------------------------------------------
+      u32 S[NR];
 #pragma unroll
-    for (int j = 0; j < NR; j++) {
-      const u32 klo = (S[j] << 16) | (u32)(2 * j);
-      const u32 khi = (S[j] & 0xffff0000u) | (u32)(2 * j + 1);
-      best = umin3(best, klo, khi);
-    }
-    const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
-    bool ok = tsum >= a.tex;
-
-    // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
-    const int in_ = mind > 0 ? mind - 1 : 1;
-    const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
-    u32 X[NQ];
-    {
-      const u32 an = (u32)(in_ & 3) * 2, ap = (u32)(ip_ & 3) * 2;
-      const u32 sel = an | ((an + 1) << 8) | (ap << 16) | ((ap + 1) << 24);
-#pragma unroll
-      for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
-    }
-    {
-      int qn = in_ >> 2, qp = ip_ >> 2;
-#pragma unroll
-      for (int n = NQ; n > 1; n >>= 1) {
-        // low half follows bit0 of qn, high half bit0 of qp; src0 = odd entry (bytes 4..7), src1 = even (0..3)
-        const u32 sel = ((qn & 1) ? 0x0504u : 0x0100u) | ((qp & 1) ? 0x07060000u : 0x03020000u);
-#pragma unroll
-        for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
-        qn >>= 1;
-        qp >>= 1;
+      for (int q = 0; q < NQ; q++) {
+        S[2 * q] = hsum<NTERM>((u32)VB[q], a3, a6, a12, a18, a24);
+        S[2 * q + 1] = hsum<NTERM>((u32)(VB[q] >> 32), a3, a6, a12, a18, a24);
       }
-    }
-    const int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
-
-    // ---- uniqueness: any d outside [mind-1, mind+1] with S[d] <= thresh rejects --------------------------------
-    if (a.uniq > 0) {
-      const int thresh = minsad + (minsad * a.uniq / 100);
-      const u32 T = (u32)min(thresh + 1, 65535);
-      const u32 T2 = T | (T << 16);
-      u32 acc = 0;
+      const int tsum = (int)hsum<NTERM>(Vt, a3, a6, a12, a18, a24);
+      if constexpr (!EXACT_ND) {
 #pragma unroll
-      for (int j = 0; j < NR; j++) acc = pk_add_sat(acc, pk_sub_sat(T2, S[j]));
-      // expected deficits of the three neighbourhood entries, per 16-bit half (even / odd buffer index)
-      const u32 dm = T - (u32)minsad;                                   // >= 1
-      const u32 dn = (mind > 0 && (u32)nn < T) ? T - (u32)nn : 0u;       // S[mind-1] exists
-      const u32 dp = (mind < a.nd - 1 && (u32)pp < T) ? T - (u32)pp : 0u; // S[mind+1] exists
-      const u32 e_same = dm, e_other = dn + dp;                          // mind's parity half / the other half
-      const u32 exp_lo = (mind & 1) ? e_other : e_same, exp_hi = (mind & 1) ? e_same : e_other;
-      ok = ok && (acc & 0xffffu) == exp_lo && (acc >> 16) == exp_hi;
-    }
+        for (int j = 0; j < NR; j++)
+          if (2 * j >= a.nd) S[j] = 0xffffffffu;
+      }
 
-    if (produces) {
-      int out = a.filtered;
-      if (ok) {
-        const int ad = pp > nn ? pp - nn : nn - pp;
-        const int den = pp + nn - 2 * minsad + ad;
-        int frac = 0;
-        if (den != 0) {
-          const u32 num = (u32)ad << 8;
-          u32 qv = (u32)((float)num / (float)den);      // |p-n|*256 < 2^24: estimate is within 1 of the quotient
-          while ((u64)qv * (u32)den > num) qv--;
-          while ((u64)(qv + 1) * (u32)den <= num) qv++;
-          frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
+      // ---- WTA: first index attaining the minimum ------------------------------------------------------------
+      // keys carry a group-local index 0..63 (inline constants for v_lshl_or_b32 / v_and_or_b32); the group base is
+      // added once per group.  Four independent v_min3_u32 chains per group keep the dependency chains short.
+      u32 best = 0xffffffffu;
+#pragma unroll
+      for (int g0 = 0; g0 < NR; g0 += 32) {
+        u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int j = g0; j < g0 + 32 && j < NR; j++) {
+          const u32 klo = (S[j] << 16) | (u32)(2 * (j - g0));
+          const u32 khi = (S[j] & 0xffff0000u) | (u32)(2 * (j - g0) + 1);
+          b[j & 3] = umin3(b[j & 3], klo, khi);
         }
-        out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
-        if (a.cost) a.cost[obase + (size_t)y * a.W] = minsad;
+        const u32 bg = min(min(b[0], b[1]), min(b[2], b[3])) + (u32)(2 * g0);
+        best = min(best, bg);
       }
-      a.disp[obase + (size_t)y * a.W] = (int16_t)out;
-    }
+      const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
+      bool ok = tsum >= a.tex;
 
-    if (y + 1 < ye) row_step(y - W2, true);
+      // ---- uniqueness (part 1): saturating sum of the deficits max(T - S[d], 0), per 16-bit half --------------
+      u32 acc = 0, T = 0;
+      if (a.uniq > 0) {
+        const int thresh = minsad + (minsad * a.uniq / 100);
+        T = (u32)min(thresh + 1, 65535);
+        const u32 T2 = T | (T << 16);
+#pragma unroll
+        for (int j = 0; j < NR; j++) acc = pk_add_sat(acc, pk_sub_sat(T2, S[j]));
+      }
+
+      // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
+      const int in_ = mind > 0 ? mind - 1 : 1;
+      const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
+      u32 X[NQ];
+      {
+        const u32 an = (u32)(in_ & 3) * 2, ap = (u32)(ip_ & 3) * 2;
+        const u32 sel = an | ((an + 1) << 8) | (ap << 16) | ((ap + 1) << 24);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
+      }
+      // S is dead from here on: fetch the leaving row now (its latency hides behind the rest of the tree, the
+      // sub-pixel arithmetic and the stores) without raising the register peak of the S-heavy phase above
+      RowRegs lv = fetch(y - W2);
+      {
+        int qn = in_ >> 2, qp = ip_ >> 2;
+#pragma unroll
+        for (int n = NQ; n > 1; n >>= 1) {
+          // low half follows bit0 of qn, high half bit0 of qp; src0 = odd entry (bytes 4..7), src1 = even (0..3)
+          const u32 sel = ((qn & 1) ? 0x0504u : 0x0100u) | ((qp & 1) ? 0x07060000u : 0x03020000u);
+#pragma unroll
+          for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
+          qn >>= 1;
+          qp >>= 1;
+        }
+      }
+      const int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
+
+      // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
+      if (a.uniq > 0) {
+        // expected deficits of the three neighbourhood entries, per 16-bit half (even / odd buffer index)
+        const u32 dm = T - (u32)minsad;                                     // >= 1
+        const u32 dn = (mind > 0 && (u32)nn < T) ? T - (u32)nn : 0u;         // S[mind-1] exists
+        const u32 dp = (mind < a.nd - 1 && (u32)pp < T) ? T - (u32)pp : 0u;  // S[mind+1] exists
+        const u32 e_same = dm, e_other = dn + dp;                            // mind's parity half / the other half
+        const u32 exp_lo = (mind & 1) ? e_other : e_same, exp_hi = (mind & 1) ? e_same : e_other;
+        ok = ok && (acc & 0xffffu) == exp_lo && (acc >> 16) == exp_hi;
+      }
+
+      if (produces) {
+        int out = a.filtered;
+        if (ok) {
+          const int ad = pp > nn ? pp - nn : nn - pp;
+          const int den = pp + nn - 2 * minsad + ad;
+          int frac = 0;
+          if (den != 0) {
+            const u32 num = (u32)ad << 8;
+            u32 qv = (u32)((float)num / (float)den);      // |p-n|*256 < 2^24: estimate is within 1 of the quotient
+            while ((u64)qv * (u32)den > num) qv--;
+            while ((u64)(qv + 1) * (u32)den <= num) qv++;
+            frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
+          }
+          out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
+          if (a.cost) a.cost[obase + (size_t)y * a.W] = minsad;
+        }
+        a.disp[obase + (size_t)y * a.W] = (int16_t)out;
+      }
+
+      if (y + 1 < ye) {
+        g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
+        apply(lv, 1);
+      }
+    }
   }
 }
 
@@ -271,8 +320,8 @@ bool sad_fast_supported(const Geom& g) {
 
 template <int ND, int NTERM>
 static hipError_t launch_t(const FastArgs& a, dim3 grid, bool exact, hipStream_t s) {
-  constexpr int NRD = ND / 16 + 1;
-  constexpr int NSLOT = ((64 + 4 + 16 * (NRD - 1) + 1) + 63) / 64 * 64;
+  constexpr int NCH = (ND / 4 + 15) / 16;
+  constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   const size_t lds = (size_t)NSLOT * 16;
   if (exact)
     hipLaunchKernelGGL((sad_fast_kernel<ND, NTERM, true>), grid, dim3(64), lds, s, a);
