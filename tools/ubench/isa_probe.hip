@@ -130,6 +130,26 @@ __global__ void __launch_bounds__(256) rate_kernel(uint32_t* out, int iters, uin
       REP8(asm volatile("v_lshl_or_b32 %0, %0, 8, %8\n v_lshl_or_b32 %1, %1, 8, %8\n v_lshl_or_b32 %2, %2, 8, %8\n v_lshl_or_b32 %3, %3, 8, %8\n"
                         "v_lshl_or_b32 %4, %4, 8, %8\n v_lshl_or_b32 %5, %5, 8, %8\n v_lshl_or_b32 %6, %6, 8, %8\n v_lshl_or_b32 %7, %7, 8, %8\n"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(p));)
+    } else if constexpr (OP == 19) {  // ds_bpermute_b32 (LDS crossbar)
+      REP8(a0 = __builtin_amdgcn_ds_bpermute((int)p, (int)a0); a1 = __builtin_amdgcn_ds_bpermute((int)p, (int)a1);
+           a2 = __builtin_amdgcn_ds_bpermute((int)p, (int)a2); a3 = __builtin_amdgcn_ds_bpermute((int)p, (int)a3);
+           a4 = __builtin_amdgcn_ds_bpermute((int)p, (int)a4); a5 = __builtin_amdgcn_ds_bpermute((int)p, (int)a5);
+           a6 = __builtin_amdgcn_ds_bpermute((int)p, (int)a6); a7 = __builtin_amdgcn_ds_bpermute((int)p, (int)a7);)
+    } else if constexpr (OP == 20) {  // bpermute + dependent v_add (the hsum pattern), 8 chains
+      REP8(a0 += __builtin_amdgcn_ds_bpermute((int)p, (int)a0); a1 += __builtin_amdgcn_ds_bpermute((int)p, (int)a1);
+           a2 += __builtin_amdgcn_ds_bpermute((int)p, (int)a2); a3 += __builtin_amdgcn_ds_bpermute((int)p, (int)a3);
+           a4 += __builtin_amdgcn_ds_bpermute((int)p, (int)a4); a5 += __builtin_amdgcn_ds_bpermute((int)p, (int)a5);
+           a6 += __builtin_amdgcn_ds_bpermute((int)p, (int)a6); a7 += __builtin_amdgcn_ds_bpermute((int)p, (int)a7);)
+    } else if constexpr (OP == 21) {  // v_mov_b32 dpp wave_shl:1
+      REP8(asm volatile("v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                        "v_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                        "v_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                        "v_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if constexpr (OP == 22) {  // v_dot2_u32_u16
+      REP8(asm volatile("v_dot2_u32_u16 %0, %8, %9, %0\n v_dot2_u32_u16 %1, %8, %9, %1\n v_dot2_u32_u16 %2, %8, %9, %2\n v_dot2_u32_u16 %3, %8, %9, %3\n"
+                        "v_dot2_u32_u16 %4, %8, %9, %4\n v_dot2_u32_u16 %5, %8, %9, %5\n v_dot2_u32_u16 %6, %8, %9, %6\n v_dot2_u32_u16 %7, %8, %9, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(p), "v"(b0));)
     } else if constexpr (OP == 18) {  // v_mqsad_u32_u8 (128-bit acc)
       // needs 4-register tuples; use 2 chains
       typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -202,7 +222,7 @@ int main() {
   uint32_t* dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4 * 2));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s CUs=%d clock=%d kHz LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate, prop.sharedMemPerBlock);
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 4}) {
     run_rate<0>("v_add_u32", dout, wps);
     run_rate<1>("v_qsad_pk_u16_u8", dout, wps);
     run_rate<2>("v_mqsad_pk_u16_u8", dout, wps);
@@ -222,6 +242,10 @@ int main() {
     run_rate<11>("v_cndmask_b32", dout, wps);
     run_rate<12>("v_alignbyte_b32", dout, wps);
     run_rate<16>("v_min_u32_sdwa", dout, wps);
+    run_rate<19>("ds_bpermute_b32", dout, wps);
+    run_rate<20>("ds_bpermute+v_add", dout, wps);
+    run_rate<21>("v_mov_dpp wave_shl:1", dout, wps);
+    run_rate<22>("v_dot2_u32_u16", dout, wps);
   }
   return 0;
 }

@@ -40,12 +40,12 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 }
 
 template <int W2>
-__global__ void __launch_bounds__(128) sad_border_kernel(BorderArgs a) {
+__global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
   constexpr int NVC = 3 * W2, WSZ = 2 * W2 + 1;
-  constexpr int RSPAN = NVC + 128;          // right bytes staged per row: rb(0) .. rb(0)+NVC+nd
+  constexpr int RSPAN = NVC + 256;          // right bytes staged per row: rb(0) .. rb(0)+NVC+nd
   __shared__ uint8_t Lbuf[2][2][NVC + 1];   // [parity][enter/leave][virtual column] (clamp already applied)
   __shared__ uint8_t Rbuf[2][2][RSPAN];
-  __shared__ int Sbuf[W2][128];
+  __shared__ int Sbuf[W2][256];
   __shared__ int Tcol[NVC];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -116,18 +116,20 @@ __global__ void __launch_bounds__(128) sad_border_kernel(BorderArgs a) {
     if (tid < NVC) Tcol[tid] = Ct;
     __syncthreads();
     for (int j = wave; j < W2; j += nwaves) {
-      const int s0 = lane < a.nd ? Sbuf[j][lane] : 0xffff;
-      const int s1 = lane + 64 < a.nd ? Sbuf[j][lane + 64] : 0xffff;
-      unsigned k0 = ((unsigned)s0 << 16) | (unsigned)lane, k1 = ((unsigned)s1 << 16) | (unsigned)(lane + 64);
-      const unsigned best = wave_min_u32(k0 < k1 ? k0 : k1);
+      unsigned bk = 0xffffffffu;
+      for (int dd = lane; dd < a.nd; dd += 64) {
+        const unsigned k = ((unsigned)Sbuf[j][dd] << 16) | (unsigned)dd;
+        bk = k < bk ? k : bk;
+      }
+      const unsigned best = wave_min_u32(bk);
       const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
       int tsum = 0;
       for (int v = 0; v < WSZ; v++) tsum += Tcol[j + v];
       bool ok = tsum >= a.tex;
       if (a.uniq > 0) {
         const int thresh = minsad + (minsad * a.uniq / 100);
-        const bool hit = (lane < a.nd && (lane < mind - 1 || lane > mind + 1) && s0 <= thresh) ||
-                         (lane + 64 < a.nd && (lane + 64 < mind - 1 || lane + 64 > mind + 1) && s1 <= thresh);
+        bool hit = false;
+        for (int dd = lane; dd < a.nd; dd += 64) hit |= (dd < mind - 1 || dd > mind + 1) && Sbuf[j][dd] <= thresh;
         ok = ok && __ballot(hit) == 0ull;
       }
       if (lane == 0) {
@@ -167,7 +169,7 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
   dim3 grid(2 * nseg, g.n);
-  dim3 block(g.nd > 64 ? 128 : 64);
+  dim3 block(64 * ((g.nd + 63) / 64));
   switch (g.w2) {
     case 4: hipLaunchKernelGGL(sad_border_kernel<4>, grid, block, 0, s, a); break;
     case 7: hipLaunchKernelGGL(sad_border_kernel<7>, grid, block, 0, s, a); break;

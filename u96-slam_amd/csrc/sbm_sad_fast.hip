@@ -14,13 +14,15 @@
 //               Entering row: V = mqsad(R, L, V).  Leaving row: V -= mqsad(R, L, 0).
 //   LDS       = the right row piece of the wavefront, expanded 16x (slot p holds bytes p..p+15) so that every lane's
 //               16-byte-aligned ds_read_b128 stream starts at its own byte offset; conflict-free (lane stride 16 B).
-//   wave ops  = horizontal window: S(c + w/2) = sum_k V(c + 3k), k < w/3, by log-step ds_bpermute adds
-//               (w = 15: T = V + V<<3 lanes, U = T + T<<6, S = U + V<<12); lanes whose partners fall outside the
-//               wavefront (the last w-3) produce nothing and are recomputed by the next strip.
+//   exchange  = horizontal window: S(c + w/2) = sum_k V(c + 3k), k < w/3: lanes publish V to LDS ([quad][lane], 8 B
+//               entries) and read the shifted copies back (conflict-free b64 traffic); lanes whose partners fall
+//               outside the wavefront (the last w-3) produce nothing and are recomputed by the next strip.
 //   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan),
 //               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree.
 // Envelope (checked on the host, everything else takes the generic kernel): w in {9,15,21,27}, nd <= 128,
 // w*w*2*cap <= 65534 (16-bit sums), 2*(maxS*uniq/100+1) < 65535, valid-ROI rows inside [w/2, H-w/2).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "sbm_common.h"
@@ -63,53 +65,44 @@ __device__ __forceinline__ u32 pk_add_sat(u32 a, u32 b) {
 }
 __device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(a, min(b, c)); }
 
-// horizontal window sum across lanes of a packed-u16 (or plain u32) register; result for centre c + w/2 lands in lane c
-template <int NTERM>
-__device__ __forceinline__ u32 hsum(u32 r, int a3, int a6, int a12, int a18, int a24) {
-  if constexpr (NTERM == 3) {
-    u32 t = r + bperm(a3, r);
-    return t + bperm(a6, r);
-  } else if constexpr (NTERM == 5) {
-    u32 t = r + bperm(a3, r);
-    u32 u = t + bperm(a6, t);
-    return u + bperm(a12, r);
-  } else if constexpr (NTERM == 7) {
-    u32 t = r + bperm(a3, r);
-    u32 u = t + bperm(a6, t);
-    u32 x = u + bperm(a12, t);
-    return x + bperm(a18, r);
-  } else {  // 9
-    u32 t = r + bperm(a3, r);
-    u32 u = t + bperm(a6, t);
-    u32 y = u + bperm(a12, u);
-    return y + bperm(a24, r);
-  }
-}
+extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NSLOT 16-byte slots, then exchange area
 
-extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // NSLOT 16-byte slots
-
-template <int ND, int NTERM, bool EXACT_ND>
-__global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
-  constexpr int NQ = ND / 4;            // disparity quads (one u64 accumulator each)
-  constexpr int NR = ND / 2;            // packed pair registers
+// NDW disparities per wavefront, NWAVES wavefronts per workgroup covering NDW*NWAVES >= nd disparities of the SAME
+// 64 columns.  NWAVES > 1 keeps the register footprint of a wavefront at NDW/2 accumulators + NDW/2 sums (4 waves per
+// SIMD at NDW = 64) at the price of two workgroup barriers per row for the WTA merge through LDS.
+template <int NDW, int NWAVES, int NTERM, bool EXACT_ND>
+__global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
+  constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
+  constexpr int NR = NDW / 2;           // packed pair registers
   constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
   constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   constexpr int NIT = NSLOT / 64;
   constexpr int WSZ = 3 * NTERM, W2 = WSZ / 2;
   constexpr int NV = 64 - (WSZ - 3);    // lanes that produce an output
+  // horizontal exchange through LDS: XCH quads at a time, XS u64 entries per quad (64 lanes + the 3*(NTERM-1) halo)
+  constexpr int XCH = NQ < 8 ? NQ : 8;
+  constexpr int XS = 64 + 3 * (NTERM - 1) + ((3 * (NTERM - 1)) & 1);
+  constexpr int XSLOT = (XCH * XS * 8 + XS * 4 + 15) / 16;
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const int d0 = wv * NDW;                              // first buffer index of this wavefront
   const int c = blockIdx.x * NV + lane;                 // this lane's column (relative to lofs): V covers c..c+2
   const int xc = c + W2;                                // centre column this lane produces
   const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
   const int ys = a.row0 + blockIdx.y * a.seg;
   const int ye = min(ys + a.seg, a.row1);
   const int pair = blockIdx.z;
-  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;               // left bytes of this lane
-  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + blockIdx.x * NV; // right piece of the wave
+  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;  // left bytes of this lane
+  // right piece of the wavefront: window of buffer index d starts at rofs + c + d
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + blockIdx.x * NV + d0;
+  // LDS carve-up (16-byte units): per wavefront [staging NSLOT][exchange XSLOT], then the WTA merge area
+  uint4* const stage_lds = fast_lds + wv * (NSLOT + XSLOT);
+  u64* const xq = reinterpret_cast<u64*>(stage_lds + NSLOT);            // [XCH quads][XS lanes] of packed 4 x u16
+  u32* const xt = reinterpret_cast<u32*>(xq + XCH * XS);                // [XS] texture column sums
+  u32* const xkey = reinterpret_cast<u32*>(fast_lds + NWAVES * (NSLOT + XSLOT));  // [2][NWAVES][64]
+  uint2* const xacc = reinterpret_cast<uint2*>(xkey + 2 * NWAVES * 64); // [2][NWAVES][64]  (deficit acc, nn | pp<<16)
   const u32 capw = (u32)a.capb * 0x01010101u;
-  const int a3 = ((lane + 3) & 63) << 2, a6 = ((lane + 6) & 63) << 2, a12 = ((lane + 12) & 63) << 2,
-            a18 = ((lane + 18) & 63) << 2, a24 = ((lane + 24) & 63) << 2;
 
   // packed 4 x u16 per quad (low dword = indices 4q,4q+1, high dword = 4q+2,4q+3).  Two arrays in ping-pong:
   // v_mqsad_pk_u16_u8 may not write a register it reads, so an entering row maps VA -> VB through the
@@ -136,21 +129,20 @@ __global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
   // mode 0: VB = VA + row (enter)   mode 1: VA = VB - row (leave)   mode 2: VA = VB + row (second half of a prime pair)
   auto apply = [&](const RowRegs& g, const int mode) {
 #pragma unroll
-    for (int it = 0; it < NIT; it++) fast_lds[it * 64 + lane] = g.r[it];
+    for (int it = 0; it < NIT; it++) stage_lds[it * 64 + lane] = g.r[it];
     const u32 pat = g.l & 0x00ffffffu;  // byte 3 = 0 -> masked by mqsad
     const u32 tv = __builtin_amdgcn_sad_u8(pat | ((u32)a.capb << 24), capw, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // 16 quads (64 disparities) at a time: 5 + 5 ds_read_b128 cover their 17 window dwords in both alignments.
-    // Chunking keeps the staged right bytes at 40 VGPRs instead of 72.
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += 16) {
       constexpr int NM = 5;
       uint4 ra[NM], rb[NM];
 #pragma unroll
       for (int m = 0; m < NM; m++) {
-        ra[m] = fast_lds[lane + 16 * (q0 / 4 + m)];
-        rb[m] = fast_lds[lane + 4 + 16 * (q0 / 4 + m)];
+        ra[m] = stage_lds[lane + 16 * (q0 / 4 + m)];
+        rb[m] = stage_lds[lane + 4 + 16 * (q0 / 4 + m)];
       }
 #pragma unroll
       for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
@@ -184,90 +176,140 @@ __global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
   };
 
   // prime: rows ys-W2 .. ys+W2-1, then the entering row of the first output row is fetched ahead
-  {
-    RowRegs g = fetch(ys - W2);
-    for (int yy = ys - W2; yy < ys + W2; yy += 2) {   // 2*W2 rows: an even count, processed in VA->VB->VA pairs
-      RowRegs n1 = fetch(yy + 1);
-      apply(g, 0);
-      RowRegs n2 = fetch(yy + 2);
-      apply(n1, 2);
-      g = n2;
+  RowRegs g = fetch(ys - W2);
+  for (int yy = ys - W2; yy < ys + W2; yy += 2) {   // 2*W2 rows: an even count, processed in VA->VB->VA pairs
+    RowRegs n1 = fetch(yy + 1);
+    apply(g, 0);
+    RowRegs n2 = fetch(yy + 2);
+    apply(n1, 2);
+    g = n2;
+  }
+  // g now holds row ys+W2
+  const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
+  for (int y = ys; y < ye; y++) {
+    apply(g, 0);
+
+    // ---- horizontal window across lanes ------------------------------------------------------------------
+    // S(c + w/2) = sum_k V(c + 3k): every lane publishes its V quads to LDS ([quad][lane], 8-byte entries: both
+    // ds_write_b64 and the shifted ds_read_b64 are conflict-free) and reads the NTERM-1 shifted copies back.
+    // (ds_bpermute_b32 would do the same without the round trip, but it costs ~24 SIMD-cycles per 4 bytes/lane on
+    // gfx950 -- measured with tools/ubench/isa_probe -- which made the kernel crossbar-bound.)
+    // Lanes >= NV read beyond lane 63 (unwritten halo entries): their sums are garbage and never stored.
+    u32 S[NR];
+    xt[lane] = Vt;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += XCH) {
+#pragma unroll
+      for (int qq = 0; qq < XCH; qq++) xq[qq * XS + lane] = VB[q0 + qq];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int qq = 0; qq < XCH; qq++) {
+        u32 lo = (u32)VB[q0 + qq], hi = (u32)(VB[q0 + qq] >> 32);
+#pragma unroll
+        for (int k = 1; k < NTERM; k++) {
+          const u64 r = xq[qq * XS + lane + 3 * k];
+          lo += (u32)r;            // packed u16 pairs: no carries, every sum stays below 65535
+          hi += (u32)(r >> 32);
+        }
+        S[2 * (q0 + qq)] = lo;
+        S[2 * (q0 + qq) + 1] = hi;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    // g now holds row ys+W2
-    const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
-    for (int y = ys; y < ye; y++) {
-      apply(g, 0);
+    if constexpr (!EXACT_ND) {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        if (d0 + 2 * j >= a.nd) S[j] = 0xffffffffu;
+    }
 
-      // ---- horizontal window across lanes ------------------------------------------------------------------
-      u32 S[NR];
+    // ---- WTA: first index attaining the minimum ------------------------------------------------------------
+    // keys carry a group-local index 0..63 (inline constants for v_lshl_or_b32 / v_and_or_b32); the group base is
+    // added once per group.  Four independent v_min3_u32 chains per group keep the dependency chains short.
+    u32 best = 0xffffffffu;
 #pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        S[2 * q] = hsum<NTERM>((u32)VB[q], a3, a6, a12, a18, a24);
-        S[2 * q + 1] = hsum<NTERM>((u32)(VB[q] >> 32), a3, a6, a12, a18, a24);
-      }
-      const int tsum = (int)hsum<NTERM>(Vt, a3, a6, a12, a18, a24);
-      if constexpr (!EXACT_ND) {
+    for (int g0 = 0; g0 < NR; g0 += 32) {
+      u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
-        for (int j = 0; j < NR; j++)
-          if (2 * j >= a.nd) S[j] = 0xffffffffu;
+      for (int j = g0; j < g0 + 32 && j < NR; j++) {
+        const u32 klo = (S[j] << 16) | (u32)(2 * (j - g0));
+        const u32 khi = (S[j] & 0xffff0000u) | (u32)(2 * (j - g0) + 1);
+        b[j & 3] = umin3(b[j & 3], klo, khi);
       }
+      const u32 bg = min(min(b[0], b[1]), min(b[2], b[3])) + (u32)(2 * g0);
+      best = min(best, bg);
+    }
+    best += (u32)d0;
+    const int par = y & 1;
+    if constexpr (NWAVES > 1) {
+      xkey[(par * NWAVES + wv) * 64 + lane] = best;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < NWAVES; w++) best = min(best, xkey[(par * NWAVES + w) * 64 + lane]);
+    }
+    const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
 
-      // ---- WTA: first index attaining the minimum ------------------------------------------------------------
-      // keys carry a group-local index 0..63 (inline constants for v_lshl_or_b32 / v_and_or_b32); the group base is
-      // added once per group.  Four independent v_min3_u32 chains per group keep the dependency chains short.
-      u32 best = 0xffffffffu;
+    // ---- uniqueness (part 1): saturating sum of the deficits max(T - S[d], 0), per 16-bit half --------------
+    u32 acc = 0, T = 0;
+    if (a.uniq > 0) {
+      const int thresh = minsad + (minsad * a.uniq / 100);
+      T = (u32)min(thresh + 1, 65535);
+      const u32 T2 = T | (T << 16);
 #pragma unroll
-      for (int g0 = 0; g0 < NR; g0 += 32) {
-        u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      for (int j = 0; j < NR; j++) acc = pk_add_sat(acc, pk_sub_sat(T2, S[j]));
+    }
+
+    // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
+    const int in_ = mind > 0 ? mind - 1 : 1;
+    const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
+    const int ln = min(max(in_ - d0, 0), NDW - 1), lp = min(max(ip_ - d0, 0), NDW - 1);  // local (clamped) indices
+    u32 X[NQ];
+    {
+      const u32 an = (u32)(ln & 3) * 2, ap = (u32)(lp & 3) * 2;
+      const u32 sel = an | ((an + 1) << 8) | (ap << 16) | ((ap + 1) << 24);
 #pragma unroll
-        for (int j = g0; j < g0 + 32 && j < NR; j++) {
-          const u32 klo = (S[j] << 16) | (u32)(2 * (j - g0));
-          const u32 khi = (S[j] & 0xffff0000u) | (u32)(2 * (j - g0) + 1);
-          b[j & 3] = umin3(b[j & 3], klo, khi);
+      for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
+    }
+    // S is dead from here on: fetch the leaving row now (its latency hides behind the rest of the tree, the
+    // merge, the sub-pixel arithmetic and the stores) without raising the register peak of the S-heavy phase
+    RowRegs lv = fetch(y - W2);
+    {
+      int qn = ln >> 2, qp = lp >> 2;
+#pragma unroll
+      for (int n = NQ; n > 1; n >>= 1) {
+        // low half follows bit0 of qn, high half bit0 of qp; src0 = odd entry (bytes 4..7), src1 = even (0..3)
+        const u32 sel = ((qn & 1) ? 0x0504u : 0x0100u) | ((qp & 1) ? 0x07060000u : 0x03020000u);
+#pragma unroll
+        for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
+        qn >>= 1;
+        qp >>= 1;
+      }
+    }
+    int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
+    u32 acc_lo = acc & 0xffffu, acc_hi = acc >> 16;
+    bool mine = true;  // does this wavefront finalise this row?
+    if constexpr (NWAVES > 1) {
+      xacc[(par * NWAVES + wv) * 64 + lane] = make_uint2(acc, X[0]);
+      __syncthreads();
+      mine = (y % NWAVES) == wv;
+      if (mine) {
+        acc_lo = acc_hi = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) {
+          const u32 aw = xacc[(par * NWAVES + w) * 64 + lane].x;
+          acc_lo += aw & 0xffffu;
+          acc_hi += aw >> 16;
         }
-        const u32 bg = min(min(b[0], b[1]), min(b[2], b[3])) + (u32)(2 * g0);
-        best = min(best, bg);
+        nn = (int)(xacc[(par * NWAVES + in_ / NDW) * 64 + lane].y & 0xffffu);   // owner wavefront of index in_
+        pp = (int)(xacc[(par * NWAVES + ip_ / NDW) * 64 + lane].y >> 16);       // owner wavefront of index ip_
       }
-      const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
+    }
+
+    if (mine) {
+      int tsum = (int)Vt;
+#pragma unroll
+      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + 3 * k];
       bool ok = tsum >= a.tex;
-
-      // ---- uniqueness (part 1): saturating sum of the deficits max(T - S[d], 0), per 16-bit half --------------
-      u32 acc = 0, T = 0;
-      if (a.uniq > 0) {
-        const int thresh = minsad + (minsad * a.uniq / 100);
-        T = (u32)min(thresh + 1, 65535);
-        const u32 T2 = T | (T << 16);
-#pragma unroll
-        for (int j = 0; j < NR; j++) acc = pk_add_sat(acc, pk_sub_sat(T2, S[j]));
-      }
-
-      // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
-      const int in_ = mind > 0 ? mind - 1 : 1;
-      const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
-      u32 X[NQ];
-      {
-        const u32 an = (u32)(in_ & 3) * 2, ap = (u32)(ip_ & 3) * 2;
-        const u32 sel = an | ((an + 1) << 8) | (ap << 16) | ((ap + 1) << 24);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
-      }
-      // S is dead from here on: fetch the leaving row now (its latency hides behind the rest of the tree, the
-      // sub-pixel arithmetic and the stores) without raising the register peak of the S-heavy phase above
-      RowRegs lv = fetch(y - W2);
-      {
-        int qn = in_ >> 2, qp = ip_ >> 2;
-#pragma unroll
-        for (int n = NQ; n > 1; n >>= 1) {
-          // low half follows bit0 of qn, high half bit0 of qp; src0 = odd entry (bytes 4..7), src1 = even (0..3)
-          const u32 sel = ((qn & 1) ? 0x0504u : 0x0100u) | ((qp & 1) ? 0x07060000u : 0x03020000u);
-#pragma unroll
-          for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
-          qn >>= 1;
-          qp >>= 1;
-        }
-      }
-      const int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
-
       // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
       if (a.uniq > 0) {
         // expected deficits of the three neighbourhood entries, per 16-bit half (even / odd buffer index)
@@ -276,9 +318,8 @@ __global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
         const u32 dp = (mind < a.nd - 1 && (u32)pp < T) ? T - (u32)pp : 0u;  // S[mind+1] exists
         const u32 e_same = dm, e_other = dn + dp;                            // mind's parity half / the other half
         const u32 exp_lo = (mind & 1) ? e_other : e_same, exp_hi = (mind & 1) ? e_same : e_other;
-        ok = ok && (acc & 0xffffu) == exp_lo && (acc >> 16) == exp_hi;
+        ok = ok && acc_lo == exp_lo && acc_hi == exp_hi;
       }
-
       if (produces) {
         int out = a.filtered;
         if (ok) {
@@ -297,18 +338,18 @@ __global__ void __launch_bounds__(64) sad_fast_kernel(FastArgs a) {
         }
         a.disp[obase + (size_t)y * a.W] = (int16_t)out;
       }
+    }
 
-      if (y + 1 < ye) {
-        g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
-        apply(lv, 1);
-      }
+    if (y + 1 < ye) {
+      g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
+      apply(lv, 1);
     }
   }
 }
 
 bool sad_fast_supported(const Geom& g) {
   if (g.wsz != 9 && g.wsz != 15 && g.wsz != 21 && g.wsz != 27) return false;
-  if (g.nd > 128) return false;
+  if (g.nd > 256) return false;
   const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
   if (maxs > 65534) return false;
   if (2 * (maxs * g.uniq / 100 + 1) >= 65535) return false;
@@ -318,29 +359,36 @@ bool sad_fast_supported(const Geom& g) {
   return true;
 }
 
-template <int ND, int NTERM>
-static hipError_t launch_t(const FastArgs& a, dim3 grid, bool exact, hipStream_t s) {
-  constexpr int NCH = (ND / 4 + 15) / 16;
+template <int NDW, int NWAVES, int NTERM>
+static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int NCH = (NDW / 4 + 15) / 16;
   constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
-  const size_t lds = (size_t)NSLOT * 16;
-  if (exact)
-    hipLaunchKernelGGL((sad_fast_kernel<ND, NTERM, true>), grid, dim3(64), lds, s, a);
+  constexpr int NQ = NDW / 4, XCH = NQ < 8 ? NQ : 8;
+  constexpr int XS = 64 + 3 * (NTERM - 1) + ((3 * (NTERM - 1)) & 1);
+  constexpr int XSLOT = (XCH * XS * 8 + XS * 4 + 15) / 16;
+  const size_t lds = (size_t)NWAVES * (NSLOT + XSLOT) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  if (a.nd == NDW * NWAVES)
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, true>), grid, dim3(64 * NWAVES), lds, s, a);
   else
-    hipLaunchKernelGGL((sad_fast_kernel<ND, NTERM, false>), grid, dim3(64), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, false>), grid, dim3(64 * NWAVES), lds, s, a);
   return hipGetLastError();
 }
 
+// mode 0 (default): 64 disparities per wavefront, nd/64 cooperating wavefronts.  mode 1: one wavefront holds all
+// (<= 128) disparities -- kept for A/B measurements (env SBM_FAST_MODE=1).
 template <int NTERM>
-static hipError_t launch_nd(const FastArgs& a, dim3 grid, hipStream_t s) {
-  if (a.nd <= 32) return launch_t<32, NTERM>(a, grid, a.nd == 32, s);
-  if (a.nd <= 64) return launch_t<64, NTERM>(a, grid, a.nd == 64, s);
-  return launch_t<128, NTERM>(a, grid, a.nd == 128, s);
+static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, hipStream_t s) {
+  if (a.nd <= 32) return launch_t<32, 1, NTERM>(a, grid, s);
+  if (a.nd <= 64) return launch_t<64, 1, NTERM>(a, grid, s);
+  if (a.nd <= 128) return mode == 1 ? launch_t<128, 1, NTERM>(a, grid, s) : launch_t<64, 2, NTERM>(a, grid, s);
+  return launch_t<64, 4, NTERM>(a, grid, s);
 }
 
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                            int* xa, int* xb, hipStream_t s) {
   *xa = *xb = 0;
   if (!sad_fast_supported(g)) return hipSuccess;
+  static const int mode = [] { const char* e = getenv("SBM_FAST_MODE"); return e ? atoi(e) : 0; }();
   FastArgs a;
   a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? cost : nullptr;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
@@ -363,10 +411,10 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   dim3 grid(strips, nseg, g.n);
   hipError_t e;
   switch (nterm) {
-    case 3: e = launch_nd<3>(a, grid, s); break;
-    case 5: e = launch_nd<5>(a, grid, s); break;
-    case 7: e = launch_nd<7>(a, grid, s); break;
-    default: e = launch_nd<9>(a, grid, s); break;
+    case 3: e = launch_nd<3>(a, grid, mode, s); break;
+    case 5: e = launch_nd<5>(a, grid, mode, s); break;
+    case 7: e = launch_nd<7>(a, grid, mode, s); break;
+    default: e = launch_nd<9>(a, grid, mode, s); break;
   }
   *xa = a.xc0; *xb = a.xc1;
   return e;
