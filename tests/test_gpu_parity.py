@@ -119,6 +119,13 @@ SMALL_CASES = [
     (64, 180, dict(num_disparities=64, block_size=15, prefilter_cap=5, texture_threshold=0, uniqueness_ratio=60, disp12_max_diff=1)),
     (64, 180, dict(num_disparities=64, block_size=15, texture_threshold=0, uniqueness_ratio=0, disp12_max_diff=0)),
     (40, 400, dict(num_disparities=128, block_size=9, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    # more than 128 disparities: four cooperating wavefronts per column strip (exact and masked disparity counts)
+    (48, 520, dict(num_disparities=256, block_size=15, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1,
+                   speckle_window_size=50, speckle_range=32)),
+    (44, 430, dict(num_disparities=160, block_size=9, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (70, 500, dict(num_disparities=208, block_size=21, min_disparity=-16, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)),
+    (90, 470, dict(num_disparities=144, block_size=27, texture_threshold=0, uniqueness_ratio=0, disp12_max_diff=1)),
+    (40, 330, dict(num_disparities=80, block_size=15, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
 ]
 
 
@@ -168,7 +175,7 @@ def test_full_hd_nd256_bit_exact(torch_cuda, pkg, oracle):
     assert_stages_equal(eng, ref, kw)
 
 
-@pytest.mark.parametrize("levels,wsz,nd", [(2, 15, 64), (3, 9, 32), (4, 21, 128), (2, 27, 64)])
+@pytest.mark.parametrize("levels,wsz,nd", [(2, 15, 64), (3, 9, 32), (4, 21, 128), (2, 27, 64), (3, 15, 256), (2, 9, 176)])
 def test_tie_heavy_images(torch_cuda, pkg, oracle, levels, wsz, nd):
     """Few grey levels and no texture/uniqueness rejection: SAD ties everywhere, so the 'first index wins' rule, the
     mirrored sub-pixel neighbours at d = 0 / nd-1 and the uniqueness bookkeeping are all exercised."""

@@ -93,15 +93,16 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 // ---------------------------------------------------------------------------------------------------------
 // Speckle filter.  cv's raster-order flood fill yields plain 4-connected components of the relation
 // "both != newVal and |a-b| <= maxDiff" (order-independent), so it is computed here as
-// run-based union-find:
-//   1. runs    one wavefront per image row: every pixel gets the index of the first pixel of its horizontal run
-//              (ballot + count-leading-zeros, carry across 64-pixel chunks); run heads are their own parents.
-//   2. merge   one thread per pixel: union the runs of vertically connected pixels, skipping contacts that the
-//              pixel to the left already made (same two runs) -- so the number of atomics ~ number of run contacts.
-//   3. count   root of every pixel; a wavefront adds each equal-root lane segment with ONE atomic, and stops
-//              adding to a component once it is known to exceed maxSpeckleSize (kills contention on large regions).
-//   4. apply   components with count <= maxSpeckleSize become newVal.
-// labels doubles as the parent array (indices within the pair's plane, -1 = invalid pixel).
+// run-based union-find.  Every kernel maps ONE WAVEFRONT TO ONE IMAGE ROW and walks it in 64-pixel chunks; run
+// membership is recomputed from the disparity row with ballots (head = valid pixel not connected to its left
+// neighbour), so only run HEADS own an entry in labels[] (parent pointer) and counts[] (run length, later the
+// component size at the root).  HBM traffic per kernel ~ one or two reads of the int16 plane.
+//   1. runs    heads: labels[head] = head, counts[head] = run length.
+//   2. merge   rows y and y+1 together: the first pixel of every vertical contact between two runs unions them
+//              (atomicMin hooks); later pixels of the same contact are skipped.
+//   3. count   heads that are not the root of their component add their run length to the root, unless the root
+//              is already known to exceed maxSpeckleSize (saturating: exact where it matters, no contention).
+//   4. apply   heads look up their component size; the decision is broadcast along the run; small -> newVal.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int uf_find(const int* L, int i) {
   int r = i;
@@ -124,105 +125,150 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   }
 }
 
+// root lookup once parents are final (after the merge kernel): plain, cacheable loads
+__device__ __forceinline__ int uf_root_final(const int* L, int i) {
+  int r = i;
+  for (int p = L[r]; p != r; p = L[r]) r = p;
+  return r;
+}
+
+// Walks one row left to right. For the 64-pixel chunk at `cb` returns, per lane: value v, valid, head and the column
+// where the lane's run starts. State carried across chunks: prev_last (value left of the chunk), carry (run start of
+// the pixel left of the chunk, -1 if it is invalid).
+struct RowWalk {
+  int prev_last, carry;
+  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; }
+  __device__ __forceinline__ void step(const int16_t* d, int cb, int W, int lane, int newval, int maxdiff, int& v,
+                                       bool& valid, bool& head, int& start) {
+    const int x = cb + lane;
+    v = x < W ? (int)d[x] : newval;
+    int pv = __shfl_up(v, 1, 64);
+    if (lane == 0) pv = prev_last;
+    valid = v != newval;
+    head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
+    const unsigned long long m = __ballot(head) & ((2ull << lane) - 1ull);
+    start = m ? cb + (63 - __clzll((long long)m)) : carry;
+    carry = __shfl(valid ? start : -1, 63, 64);
+    prev_last = __shfl(v, 63, 64);
+  }
+};
+
+#define SPK_ROW_SETUP                                          \
+  const int lane = threadIdx.x & 63;                           \
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);           \
+  const size_t plane_off = (size_t)blockIdx.y * W * H;         \
+  (void)lane;
+
 // grid: (ceil(H/4), n), block 256 = 4 wavefronts = 4 rows
 __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
                                                             int* __restrict__ counts, int W, int H, int newval,
                                                             int maxdiff) {
-  const int lane = threadIdx.x & 63;
-  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  SPK_ROW_SETUP
   if (y >= H) return;
-  const size_t po = (size_t)blockIdx.y * W * H + (size_t)y * W;
-  const int16_t* d = disp + po;
-  int* L = labels + po;
-  int* C = counts + po;
-  int carry = -1;         // run start of the pixel just left of this chunk (only used when connected to it)
-  int prev_last = newval; // value of the pixel just left of this chunk
-  for (int cb = 0; cb < W; cb += 64) {
+  const int16_t* d = disp + plane_off + (size_t)y * W;
+  int* L = labels + plane_off;
+  int* C = counts + plane_off;
+  // right to left: every head learns the distance to the next boundary (head or invalid pixel or row end)
+  int next_b = W;
+  for (int cb = ((W - 1) / 64) * 64; cb >= 0; cb -= 64) {
     const int x = cb + lane;
-    const bool in = x < W;
-    const int v = in ? (int)d[x] : newval;
+    const int v = x < W ? (int)d[x] : newval;
     int pv = __shfl_up(v, 1, 64);
-    if (lane == 0) pv = prev_last;
+    if (lane == 0) pv = cb > 0 ? (int)d[cb - 1] : newval;
     const bool valid = v != newval;
-    const bool joined = valid && pv != newval && abs(v - pv) <= maxdiff;  // connected to the left neighbour
-    const bool head = valid && !joined;
-    const unsigned long long m = __ballot(head) & ((2ull << lane) - 1ull);
-    const int start = m ? cb + (63 - __clzll((long long)m)) : carry;
-    if (in) {
-      L[x] = valid ? y * W + start : -1;
-      C[x] = 0;
+    const bool head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
+    const unsigned long long bm = __ballot(!valid || head);  // lanes beyond W count as invalid = boundary
+    const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
+    const int nb = above ? x + __ffsll((long long)above) : next_b;
+    if (head) {
+      L[y * W + x] = y * W + x;
+      C[y * W + x] = nb - x;
     }
-    carry = __shfl(valid ? start : -1, 63, 64);
-    prev_last = __shfl(v, 63, 64);
+    if (bm) next_b = cb + __ffsll((long long)bm) - 1;
   }
 }
 
 __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
                                                              int W, int H, int newval, int maxdiff) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int npix = W * H;
-  if (i >= npix - W) return;  // last row has no row below
-  const size_t po = (size_t)blockIdx.y * npix;
-  const int16_t* d = disp + po;
-  int* L = labels + po;
-  const int v = d[i], u = d[i + W];
-  if (v == newval || u == newval || abs(v - u) > maxdiff) return;
-  const int la = L[i], lb = L[i + W];
-  const int x = i % W;
-  if (x > 0) {
-    const int v1 = d[i - 1], u1 = d[i - 1 + W];
-    if (v1 != newval && u1 != newval && abs(v1 - u1) <= maxdiff && L[i - 1] == la && L[i - 1 + W] == lb) return;
+  SPK_ROW_SETUP
+  if (y >= H - 1) return;
+  const int16_t* du = disp + plane_off + (size_t)y * W;
+  const int16_t* dd = du + W;
+  int* L = labels + plane_off;
+  RowWalk up, dn;
+  up.init(newval);
+  dn.init(newval);
+  bool prev_cd = false;  // vertical contact at the pixel left of the chunk
+  for (int cb = 0; cb < W; cb += 64) {
+    int vu, vd, su, sd;
+    bool valu, vald, hu, hd;
+    up.step(du, cb, W, lane, newval, maxdiff, vu, valu, hu, su);
+    dn.step(dd, cb, W, lane, newval, maxdiff, vd, vald, hd, sd);
+    const bool cd = valu && vald && abs(vu - vd) <= maxdiff;
+    bool pcd = __shfl_up((int)cd, 1, 64) != 0;
+    if (lane == 0) pcd = prev_cd;
+    // same two runs as the pixel to the left and that pixel already made the contact -> nothing new
+    if (cd && !(pcd && !hu && !hd)) uf_union(L, y * W + su, (y + 1) * W + sd);
+    prev_cd = __shfl((int)cd, 63, 64) != 0;
   }
-  uf_union(L, la, lb);
 }
 
-__global__ void __launch_bounds__(256) speckle_count_kernel(int* __restrict__ labels, int* __restrict__ counts, int npix,
-                                                             int maxsize) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const size_t po = (size_t)blockIdx.y * npix;
-  int* L = labels + po;
-  int r = -1;
-  if (i < npix) {
-    const int l = L[i];
-    if (l >= 0) {
-      // the merge kernel has finished: parents are final, so plain (L1-cacheable) loads are safe here; concurrent
-      // shortcut stores below only ever write a node's final root
-      r = l;
-      for (int p2 = L[r]; p2 != r; p2 = L[r]) r = p2;
-      L[i] = r;
+__global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __restrict__ disp, const int* __restrict__ labels,
+                                                             int* __restrict__ counts, int W, int H, int newval,
+                                                             int maxdiff, int maxsize) {
+  SPK_ROW_SETUP
+  if (y >= H) return;
+  const int16_t* d = disp + plane_off + (size_t)y * W;
+  const int* L = labels + plane_off;
+  int* C = counts + plane_off;
+  RowWalk rw;
+  rw.init(newval);
+  for (int cb = 0; cb < W; cb += 64) {
+    int v, st;
+    bool valid, head;
+    rw.step(d, cb, W, lane, newval, maxdiff, v, valid, head, st);
+    if (head) {
+      const int self = y * W + cb + lane;
+      const int r = uf_root_final(L, self);
+      if (r != self && __hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize)
+        atomicAdd(C + r, C[self]);
     }
-  }
-  int pr = __shfl_up(r, 1, 64);
-  const bool seg = lane == 0 || pr != r;
-  const unsigned long long m = __ballot(seg);
-  if (seg && r >= 0) {
-    const unsigned long long above = lane == 63 ? 0ull : (m >> (lane + 1));
-    const int len = above ? __ffsll((long long)above) : 64 - lane;
-    int* c = counts + po + r;
-    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(c, len);
   }
 }
 
 __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict__ disp, const int* __restrict__ labels,
-                                                             const int* __restrict__ counts, int npix, int newval,
-                                                             int maxsize) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= npix) return;
-  const size_t po = (size_t)blockIdx.y * npix;
-  const int r = labels[po + i];
-  if (r >= 0 && counts[po + r] <= maxsize) disp[po + i] = (int16_t)newval;
+                                                             const int* __restrict__ counts, int W, int H, int newval,
+                                                             int maxdiff, int maxsize) {
+  SPK_ROW_SETUP
+  if (y >= H) return;
+  int16_t* d = disp + plane_off + (size_t)y * W;
+  const int* L = labels + plane_off;
+  const int* C = counts + plane_off;
+  RowWalk rw;
+  rw.init(newval);
+  int carry_kill = 0;  // decision of the run that contains the pixel left of the chunk
+  for (int cb = 0; cb < W; cb += 64) {
+    int v, st;
+    bool valid, head;
+    rw.step(d, cb, W, lane, newval, maxdiff, v, valid, head, st);
+    int kill = 0;
+    if (head) kill = C[uf_root_final(L, y * W + cb + lane)] <= maxsize;
+    const int from = __shfl(kill, st >= cb ? st - cb : 0, 64);   // decision of this lane's run head (if in the chunk)
+    const int mine = valid ? (st >= cb ? from : carry_kill) : 0;
+    if (mine) d[cb + lane] = (int16_t)newval;   // rw keeps the ORIGINAL value of the chunk's last pixel for the next chunk
+    carry_kill = __shfl(mine, 63, 64);
+  }
 }
 
 hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
                           hipStream_t s) {
-  const int npix = g.W * g.H;
-  dim3 grid((npix + 255) / 256, g.n);
-  hipLaunchKernelGGL(speckle_runs_kernel, dim3((g.H + 3) / 4, g.n), dim3(256), 0, s, disp, labels, counts, g.W, g.H,
-                     g.filtered, max_diff);
+  dim3 grid((g.H + 3) / 4, g.n);
+  hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff);
   hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
-  hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, labels, counts, npix, max_size);
-  hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, npix, g.filtered, max_size);
+  hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
+                     max_size);
+  hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
+                     max_size);
   return hipGetLastError();
 }
 

@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   constexpr int NV = 64 - (WSZ - 3);    // lanes that produce an output
   // horizontal exchange through LDS: XCH quads at a time, XS u64 entries per quad (64 lanes + the 3*(NTERM-1) halo)
   constexpr int XCH = NQ < 8 ? NQ : 8;
-  constexpr int XS = 64 + 3 * (NTERM - 1) + ((3 * (NTERM - 1)) & 1);
-  constexpr int XSLOT = (XCH * XS * 8 + XS * 4 + 15) / 16;
+  constexpr int XS = 64 + 3 * (NTERM - 1);
+  constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
 
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + blockIdx.x * NV + d0;
   // LDS carve-up (16-byte units): per wavefront [staging NSLOT][exchange XSLOT], then the WTA merge area
   uint4* const stage_lds = fast_lds + wv * (NSLOT + XSLOT);
-  u64* const xq = reinterpret_cast<u64*>(stage_lds + NSLOT);            // [XCH quads][XS lanes] of packed 4 x u16
-  u32* const xt = reinterpret_cast<u32*>(xq + XCH * XS);                // [XS] texture column sums
+  uint4* const xq = stage_lds + NSLOT;                                  // [XCH/2 quad pairs][XS lanes], 8 x u16 each
+  u32* const xt = reinterpret_cast<u32*>(xq + (XCH / 2) * XS);          // [XS] texture column sums
   u32* const xkey = reinterpret_cast<u32*>(fast_lds + NWAVES * (NSLOT + XSLOT));  // [2][NWAVES][64]
   uint2* const xacc = reinterpret_cast<uint2*>(xkey + 2 * NWAVES * 64); // [2][NWAVES][64]  (deficit acc, nn | pp<<16)
   const u32 capw = (u32)a.capb * 0x01010101u;
@@ -199,21 +199,30 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
     xt[lane] = Vt;
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += XCH) {
+      // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
 #pragma unroll
-      for (int qq = 0; qq < XCH; qq++) xq[qq * XS + lane] = VB[q0 + qq];
+      for (int qq = 0; qq < XCH; qq += 2) {
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
+        xq[(qq / 2) * XS + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int qq = 0; qq < XCH; qq++) {
-        u32 lo = (u32)VB[q0 + qq], hi = (u32)(VB[q0 + qq] >> 32);
+      for (int qq = 0; qq < XCH; qq += 2) {
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
+        u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
 #pragma unroll
         for (int k = 1; k < NTERM; k++) {
-          const u64 r = xq[qq * XS + lane + 3 * k];
-          lo += (u32)r;            // packed u16 pairs: no carries, every sum stays below 65535
-          hi += (u32)(r >> 32);
+          const uint4 r = xq[(qq / 2) * XS + lane + 3 * k];
+          s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
+          s1 += r.y;
+          s2 += r.z;
+          s3 += r.w;
         }
-        S[2 * (q0 + qq)] = lo;
-        S[2 * (q0 + qq) + 1] = hi;
+        S[2 * (q0 + qq)] = s0;
+        S[2 * (q0 + qq) + 1] = s1;
+        S[2 * (q0 + qq) + 2] = s2;
+        S[2 * (q0 + qq) + 3] = s3;
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -364,8 +373,8 @@ static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
   constexpr int NCH = (NDW / 4 + 15) / 16;
   constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   constexpr int NQ = NDW / 4, XCH = NQ < 8 ? NQ : 8;
-  constexpr int XS = 64 + 3 * (NTERM - 1) + ((3 * (NTERM - 1)) & 1);
-  constexpr int XSLOT = (XCH * XS * 8 + XS * 4 + 15) / 16;
+  constexpr int XS = 64 + 3 * (NTERM - 1);
+  constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
   const size_t lds = (size_t)NWAVES * (NSLOT + XSLOT) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   if (a.nd == NDW * NWAVES)
     hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, true>), grid, dim3(64 * NWAVES), lds, s, a);
