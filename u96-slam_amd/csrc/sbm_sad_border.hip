@@ -65,11 +65,31 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
   for (int v = 0; v < NVC; v++) C[v] = 0;
   int Ct = 0;  // thread v < NVC: vertical sum of |L - cap| of virtual column v
 
-  auto stage = [&](int par, int which, int y) {
+  // Staging is split into fetch (global -> registers, issued one row ahead so its latency hides behind the previous
+  // row's arithmetic) and commit (registers -> LDS).  Per thread: up to RPT right bytes and one left byte per row.
+  constexpr int RPT = (NVC + 256 + 63) / 64;   // enough for the smallest block (64 threads)
+  struct Staged { uint8_t r[RPT]; uint8_t l; };
+  const int nstage = NVC + a.nd;
+  const int lcol = a.lofs + clampi(xfirst + (tid < NVC ? tid : 0), -a.lofs, a.W - a.lofs - 1);
+  auto fetch = [&](int y) {
+    Staged g;
     const uint8_t* lrow = pl + (size_t)y * a.pitch;
     const uint8_t* rrow = pr + (size_t)y * a.pitch + rb0;
-    for (int i = tid; i < NVC + a.nd; i += blockDim.x) Rbuf[par][which][i] = rrow[i];
-    if (tid < NVC) Lbuf[par][which][tid] = lrow[a.lofs + clampi(xfirst + tid, -a.lofs, a.W - a.lofs - 1)];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int i = tid + k * (int)blockDim.x;
+      g.r[k] = i < nstage ? rrow[i] : (uint8_t)0;
+    }
+    g.l = lrow[lcol];
+    return g;
+  };
+  auto commit = [&](const Staged& g, int par, int which) {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int i = tid + k * (int)blockDim.x;
+      if (i < nstage) Rbuf[par][which][i] = g.r[k];
+    }
+    if (tid < NVC) Lbuf[par][which][tid] = g.l;
   };
   // add (sign=+1) or remove (-1) one staged row
   auto accumulate = [&](int par, int which, int sign) {
@@ -88,17 +108,24 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
   };
 
   int par = 0;
+  Staged ge = fetch(ys - W2);
   for (int yy = ys - W2; yy < ys + W2; yy++) {
-    stage(par, 0, yy);
+    commit(ge, par, 0);
     __syncthreads();
+    ge = fetch(yy + 1);          // the last one fetched here is row ys+W2, the first output row's entering row
     accumulate(par, 0, +1);
     par ^= 1;
   }
 
+  Staged gl = ge;  // placeholder until there is a leaving row
   for (int y = ys; y < ye; y++) {
-    stage(par, 0, y + W2);
-    if (y > ys) stage(par, 1, y - W2 - 1);
+    commit(ge, par, 0);
+    if (y > ys) commit(gl, par, 1);
     __syncthreads();
+    if (y + 1 < ye) {            // next iteration's rows: entering y+1+W2, leaving y-W2
+      ge = fetch(y + 1 + W2);
+      gl = fetch(y - W2);
+    }
     accumulate(par, 0, +1);
     if (y > ys) accumulate(par, 1, -1);
     par ^= 1;

@@ -96,11 +96,14 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;  // left bytes of this lane
   // right piece of the wavefront: window of buffer index d starts at rofs + c + d
   const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + blockIdx.x * NV + d0;
-  // LDS carve-up (16-byte units): per wavefront [staging NSLOT][exchange XSLOT], then the WTA merge area
-  uint4* const stage_lds = fast_lds + wv * (NSLOT + XSLOT);
-  uint4* const xq = stage_lds + NSLOT;                                  // [XCH/2 quad pairs][XS lanes], 8 x u16 each
+  // LDS carve-up (16-byte units): per wavefront one region of WSLOT slots that serves first as the staging area of a
+  // row (apply) and then as the exchange area of the horizontal window -- never live together, and a wavefront's LDS
+  // operations execute in order -- followed by the WTA merge area of the workgroup.
+  constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
+  uint4* const stage_lds = fast_lds + wv * WSLOT;
+  uint4* const xq = stage_lds;                                          // [XCH/2 quad pairs][XS lanes], 8 x u16 each
   u32* const xt = reinterpret_cast<u32*>(xq + (XCH / 2) * XS);          // [XS] texture column sums
-  u32* const xkey = reinterpret_cast<u32*>(fast_lds + NWAVES * (NSLOT + XSLOT));  // [2][NWAVES][64]
+  u32* const xkey = reinterpret_cast<u32*>(fast_lds + NWAVES * WSLOT);  // [2][NWAVES][64]
   uint2* const xacc = reinterpret_cast<uint2*>(xkey + 2 * NWAVES * 64); // [2][NWAVES][64]  (deficit acc, nn | pp<<16)
   const u32 capw = (u32)a.capb * 0x01010101u;
 
@@ -375,7 +378,8 @@ static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
   constexpr int NQ = NDW / 4, XCH = NQ < 8 ? NQ : 8;
   constexpr int XS = 64 + 3 * (NTERM - 1);
   constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
-  const size_t lds = (size_t)NWAVES * (NSLOT + XSLOT) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
+  const size_t lds = (size_t)NWAVES * WSLOT * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   if (a.nd == NDW * NWAVES)
     hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, true>), grid, dim3(64 * NWAVES), lds, s, a);
   else
