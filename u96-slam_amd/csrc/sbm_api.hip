@@ -294,6 +294,12 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   if (any_rows) {
     // every computed column (valid or not) must hold a defined value before the LR check reads it
     int fa = 0, fb = 0;
+    // 16-bit cost plane when every producer is a 16-bit-sum kernel (fast + border); the generic kernel needs int32
+    {
+      const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
+      g.cost16 = sad_fast_supported(g) && g.xend - (xhi - g.w2 + 1) == g.w2;
+      h->last = g;
+    }
     if (sad_fast_supported(g)) {
       HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &fa, &fb, h->stream));
     }
@@ -358,6 +364,16 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes) {
   if (which == 2) {
     if (!h->cost) return SBM_ERR_UNSUPPORTED;
     if (dst_bytes < npix * sizeof(int32_t)) return SBM_ERR_SIZE;
+    if (g.cost16) {
+      uint16_t* tmp = (uint16_t*)malloc(npix * sizeof(uint16_t));
+      if (!tmp) return SBM_ERR_NOMEM;
+      hipError_t e = hipMemcpy(tmp, h->cost, npix * sizeof(uint16_t), hipMemcpyDeviceToHost);
+      if (e == hipSuccess)
+        for (size_t i = 0; i < npix; i++) ((int32_t*)dst)[i] = tmp[i];
+      free(tmp);
+      HIPCHK(h, e);
+      return SBM_OK;
+    }
     HIPCHK(h, hipMemcpy(dst, h->cost, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
     return SBM_OK;
   }

@@ -22,6 +22,7 @@ struct Geom {
   int row0, row1;      // valid-ROI rows [row0,row1)
   int col0, col1;      // valid-ROI columns [col0,col1)
   int want_cost;       // disp12_max_diff >= 0
+  int cost16;          // the cost plane holds uint16 (fast + border kernels: sums <= 65534) instead of int32
 };
 
 // Prefiltered planes store value+1 (range 1..2*cap+1 <= 127) so that 0 can act as the "masked byte" of

@@ -16,8 +16,9 @@ namespace sbm {
 // ---------------------------------------------------------------------------------------------------------
 struct LrArgs {
   const int16_t* disp_pre;
-  const int32_t* cost;
+  const void* cost;   // uint16 plane when cost16, else int32
   int16_t* disp_out;
+  int cost16;
   int W, H, mindisp, nd, tol, filtered, row0, row1, col0, col1, do_lr;
   int cx0, cx1;  // columns [cx0,cx1) of disp_pre were computed; the rest reads as FILTERED
 };
@@ -38,7 +39,8 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
     for (int x = threadIdx.x; x < a.W; x += 256) out[x] = (x >= lo && x < hi) ? dp[x] : (int16_t)a.filtered;
     return;
   }
-  const int32_t* cp = a.cost + base;
+  const uint16_t* cp16 = static_cast<const uint16_t*>(a.cost) + base;
+  const int32_t* cp32 = static_cast<const int32_t*>(a.cost) + base;
   const int INV = a.filtered;
   const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(a.W + min(a.mindisp, 0), a.cx1);
   for (int x = threadIdx.x; x < a.W; x += 256) lr_keys[x] = ~0ull;
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
     if (d == INV) continue;
     const int x2 = x - ((d + 8) >> 4);
     if (x2 >= 0 && x2 < a.W)
-      atomicMin(&lr_keys[x2], ((unsigned long long)(unsigned)cp[x] << 32) | (unsigned)x);
+      atomicMin(&lr_keys[x2], ((unsigned long long)(a.cost16 ? (unsigned)cp16[x] : (unsigned)cp32[x]) << 32) | (unsigned)x);
   }
   __syncthreads();
   for (int x = threadIdx.x; x < a.W; x += 256) {
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
                           int disp12_max_diff, hipStream_t s) {
   LrArgs a;
-  a.disp_pre = disp_pre; a.cost = cost; a.disp_out = disp_out;
+  a.disp_pre = disp_pre; a.cost = cost; a.disp_out = disp_out; a.cost16 = g.cost16;
   a.W = g.W; a.H = g.H; a.mindisp = g.mindisp; a.nd = g.nd; a.tol = disp12_max_diff * 16; a.filtered = g.filtered;
   a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
   a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;

@@ -21,7 +21,8 @@ struct BorderArgs {
   const uint8_t* pf_l;
   const uint8_t* pf_r;
   int16_t* disp;
-  int32_t* cost;
+  void* cost;      // uint16 plane when cost16, else int32
+  int cost16;
   int W, H, pitch, padl, plane;
   int nd, mindisp, lofs, rofs, tex, uniq, filtered, capb;
   int row0, row1, seg;
@@ -168,7 +169,10 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
           const int ad = p > n ? p - n : n - p;
           const int den = p + n - 2 * minsad + ad;
           out = ((a.nd - mind - 1 + a.mindisp) * 256 + (den != 0 ? (p - n) * 256 / den : 0) + 15) >> 4;
-          if (a.cost) a.cost[o] = minsad;
+          if (a.cost) {
+            if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)minsad;
+            else static_cast<int32_t*>(a.cost)[o] = minsad;
+          }
         }
         a.disp[o] = (int16_t)out;
       }
@@ -184,7 +188,7 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   // left side = columns [0,xa), right side = [xb,xend); both hold exactly w/2 columns when the fast range exists
   if (xa != g.w2 || g.xend - xb != g.w2) return hipErrorInvalidValue;
   BorderArgs a;
-  a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? cost : nullptr;
+  a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? cost : nullptr; a.cost16 = g.cost16;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
   a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex; a.uniq = g.uniq;
   a.filtered = g.filtered; a.capb = g.cap + kPfBias;

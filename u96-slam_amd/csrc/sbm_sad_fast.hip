@@ -37,10 +37,11 @@ struct FastArgs {
   const uint8_t* pf_l;
   const uint8_t* pf_r;
   int16_t* disp;
-  int32_t* cost;
+  uint16_t* cost;            // 16-bit cost plane (sums fit by the envelope)
   int W, H, pitch, padl, plane;
   int nd, mindisp, lofs, rofs, tex, uniq, filtered, capb;
   int row0, row1, seg;       // rows [row0,row1) in segments of `seg`
+  int strips, nseg, npairs;  // grid decomposition (1-D grid of strips*nseg*npairs workgroups)
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
 };
 
@@ -87,15 +88,36 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int d0 = wv * NDW;                              // first buffer index of this wavefront
-  const int c = blockIdx.x * NV + lane;                 // this lane's column (relative to lofs): V covers c..c+2
+  // XCD-aware decode of the 1-D workgroup id: consecutive ids go round-robin over the 8 XCDs (each with its own
+  // 4 MiB L2), so give XCD k the pairs k, k+8, ...: all strips and row segments of a pair then share one L2.
+  // (Placement only affects speed; any mapping is correct.)
+  const int bpp = a.strips * a.nseg;                    // workgroups per pair
+  int strip, segi, pair;
+  {
+    const int b = blockIdx.x;
+    const int full = (a.npairs / 8) * 8 * bpp;          // ids covered by complete groups of 8 pairs
+    int p, inner;
+    if (b < full) {
+      const int xcd = b & 7, k = b >> 3;
+      p = (k / bpp) * 8 + xcd;
+      inner = k % bpp;
+    } else {
+      const int r = b - full;
+      p = (a.npairs / 8) * 8 + r / bpp;
+      inner = r % bpp;
+    }
+    pair = p;
+    strip = inner % a.strips;
+    segi = inner / a.strips;
+  }
+  const int c = strip * NV + lane;                      // this lane's column (relative to lofs): V covers c..c+2
   const int xc = c + W2;                                // centre column this lane produces
   const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
-  const int ys = a.row0 + blockIdx.y * a.seg;
+  const int ys = a.row0 + segi * a.seg;
   const int ye = min(ys + a.seg, a.row1);
-  const int pair = blockIdx.z;
   const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;  // left bytes of this lane
   // right piece of the wavefront: window of buffer index d starts at rofs + c + d
-  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + blockIdx.x * NV + d0;
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + strip * NV + d0;
   // LDS carve-up (16-byte units): per wavefront one region of WSLOT slots that serves first as the staging area of a
   // row (apply) and then as the exchange area of the horizontal window -- never live together, and a wavefront's LDS
   // operations execute in order -- followed by the WTA merge area of the workgroup.
@@ -346,7 +368,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
             frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
           }
           out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
-          if (a.cost) a.cost[obase + (size_t)y * a.W] = minsad;
+          if (a.cost) a.cost[obase + (size_t)y * a.W] = (uint16_t)minsad;
         }
         a.disp[obase + (size_t)y * a.W] = (int16_t)out;
       }
@@ -403,7 +425,7 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   if (!sad_fast_supported(g)) return hipSuccess;
   static const int mode = [] { const char* e = getenv("SBM_FAST_MODE"); return e ? atoi(e) : 0; }();
   FastArgs a;
-  a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? cost : nullptr;
+  a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? reinterpret_cast<uint16_t*>(cost) : nullptr;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
   a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex; a.uniq = g.uniq;
   a.filtered = g.filtered; a.capb = g.cap + kPfBias;
@@ -421,7 +443,8 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
-  dim3 grid(strips, nseg, g.n);
+  a.strips = strips; a.nseg = nseg; a.npairs = g.n;
+  dim3 grid((unsigned)strips * nseg * g.n);
   hipError_t e;
   switch (nterm) {
     case 3: e = launch_nd<3>(a, grid, mode, s); break;
