@@ -114,7 +114,7 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
 int sbm_synchronize(sbm_handle* h);
 
 /* Intermediate planes of the LAST sbm_compute_device call, for stage-by-stage parity tests.
- * which: 0 = prefiltered left (u8), 1 = prefiltered right (u8), 2 = WTA cost plane (int16, valid only
+ * which: 0 = prefiltered left (u8), 1 = prefiltered right (u8), 2 = WTA cost plane (int32, valid only
  * where the pre-LR disparity is valid and disp12_max_diff >= 0), 3 = disparity before LR/speckle (int16).
  * Copies n*height*width elements into host memory `dst`. */
 int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
