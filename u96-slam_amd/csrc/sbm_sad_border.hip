@@ -11,6 +11,8 @@
 // sums over v.  That is O(1) work per (virtual column, disparity, row) instead of the generic kernel's O(w).
 // One workgroup = one side of one row segment of one pair; threads = disparities; WTA per output column is a
 // wavefront reduction over LDS-resident sums.  Same envelope as the fast kernel (16-bit-safe sums, nd <= 128).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "sbm_common.h"
@@ -196,7 +198,9 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   a.xo[0] = 0; a.xo[1] = xb;
   const int rows = g.row1 - g.row0;
   // short segments: each row costs a latency-bound staging round trip, so favour many concurrent workgroups
-  int nseg = std::max(1, std::min(rows / (2 * g.wsz), 16));
+  static const int seg_rows_env = [] { const char* e = getenv("SBM_BORDER_SEG"); return e ? atoi(e) : 0; }();
+  const int seg_rows = seg_rows_env > 0 ? seg_rows_env : 12;  // measured optimum 10..16 rows (KITTI w15, 640x480 w21)
+  int nseg = std::max(1, rows / seg_rows);
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
   dim3 grid(2 * nseg, g.n);
