@@ -128,6 +128,37 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
 
+/* ---- consumers of the disparity map --------------------------------------------
+ * Device-side versions of what the reference does with the map right after compute(), so that only the small
+ * results have to cross PCIe:
+ *   decimation      SensorData::setFeatures, src/slam/src/core/SensorData.cpp:50-58  (keeps every scale-th pixel)
+ *   reprojection    projectDisparityTo3D, src/slam/src/core/Stereo.cpp:157-182, as used on the decimated map by
+ *                   buildOccupancyGridMap, src/slam/src/core/main.cpp:522-553 (pt2d = (col*scale, row*scale))
+ *   keypoint depth  generateKeypoints3DStereo (dense-map branch), src/slam/src/core/Stereo.cpp:53-117
+ * Arithmetic follows the C++ source operation by operation (float / double exactly where the reference uses them,
+ * no fused multiply-add), so results are bit-identical to the reference's expressions. Invalid points are NaN. */
+typedef struct sbm_stereo_model {
+  double fx_l, fy_l, cx_l, cy_l, Tx_l;  /* StereoCameraModel P[0] entries (include/core/StereoCameraModel.h:25-29) */
+  double fx_r, fy_r, cx_r, Tx_r;        /* P[1] entries (:30-34)                                                   */
+  float local[12];                      /* localTransform r11 r12 r13 o14 / r21.. / r31.. (Transform.h:38-41)       */
+  int32_t has_local;                    /* 0 = localTransform().isNull()                                            */
+} sbm_stereo_model;
+
+/* out[p][r][c] = disp[p][r*scale][c*scale]; out planes are (height/scale) x (width/scale), densely packed. */
+int sbm_decimate_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale, void* d_out, int sync);
+
+/* xyz[p][r][c] = projectDisparityTo3D((c*scale, r*scale), disp[p][r][c]/16.0f, model), then localTransform if
+ * apply_local != 0 and the model has one; NaN triple where the disparity is <= 0 or the point is not finite.
+ * width/height are those of the (possibly decimated) map; d_xyz holds n*height*width*3 floats. */
+int sbm_reproject_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale,
+                         const sbm_stereo_model* model, int apply_local, void* d_xyz, int sync);
+
+/* 3-D points of nk keypoints of ONE full-resolution disparity plane: for keypoint (x,y) the disparity is
+ * disp[(int)y][(int)x]/16.0f (negative -> 0 -> invalid), range-checked with min_depth / max_depth exactly as
+ * generateKeypoints3DStereo does, then localTransform. d_kpts: nk*2 floats (x,y); d_xyz: nk*3 floats. */
+int sbm_keypoints3d_device(sbm_handle* h, const void* d_disp, int width, int height, const void* d_kpts, int nk,
+                           const sbm_stereo_model* model, float min_depth, float max_depth, void* d_xyz, int sync);
+
 /* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours. */
 void* sbm_stream(sbm_handle* h);
 

@@ -10,6 +10,7 @@
 #include "sbm_oracle.h"
 
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -559,4 +560,88 @@ int sbmo_compute_batch(const sbm_params* p, int n, const uint8_t* left, const ui
     }
   }
   return status;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Consumers of the disparity map, restated from the reference's own sources (these ARE in /root/reference,
+ * so this part of the oracle follows in-tree code, operation by operation; compiled with -ffp-contract=off).
+ * ------------------------------------------------------------------------------------------------ */
+/* SensorData::setFeatures, src/slam/src/core/SensorData.cpp:50-58 */
+void sbmo_decimate(const int16_t* disp, int width, int height, int scale, int16_t* out) {
+  const int wd = width / scale, hd = height / scale;
+  for (int r = 0; r < hd; r++)
+    for (int c = 0; c < wd; c++) out[(size_t)r * wd + c] = disp[(size_t)(r * scale) * width + c * scale];
+}
+
+typedef struct { float x, y, z; } pt3;
+
+/* projectDisparityTo3D, src/slam/src/core/Stereo.cpp:157-182 */
+static pt3 project_disparity(float px, float py, float disp, const sbm_stereo_model* m) {
+  pt3 p;
+  if (disp > 0.0f) {
+    float c = (float)(m->cx_r - m->cx_l);
+    /* volatile: gcc -O3's SLP vectoriser otherwise keeps Wx/Wy in double across the products below (observed with
+     * gcc 11, -march=x86-64-v3), which is not what the C++ source (float Wx, Wy) computes */
+    volatile float Wx = (float)((m->Tx_l / m->fx_l - m->Tx_r / m->fx_r) / (disp + c));
+    volatile float Wy = (float)((m->Tx_l / m->fy_l - m->Tx_r / m->fy_r) / (disp + c));
+    p.x = (float)((px - m->cx_l) * Wx);
+    p.y = (float)((py - m->cy_l) * Wy);
+    p.z = (float)(m->fx_l * Wx);
+  } else {
+    p.x = p.y = p.z = NAN;
+  }
+  return p;
+}
+
+/* isFinite / transformPoint, src/slam/src/core/Stereo.cpp:184-199 */
+static int finite3(pt3 p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+static pt3 transform_point(pt3 p, const float* t) {
+  pt3 r;
+  r.x = t[0] * p.x + t[1] * p.y + t[2] * p.z + t[3];
+  r.y = t[4] * p.x + t[5] * p.y + t[6] * p.z + t[7];
+  r.z = t[8] * p.x + t[9] * p.y + t[10] * p.z + t[11];
+  return r;
+}
+
+/* the per-pixel part of buildOccupancyGridMap, src/slam/src/core/main.cpp:522-553 */
+void sbmo_reproject(const int16_t* disp, int width, int height, int scale, const sbm_stereo_model* m, int apply_local,
+                    float* xyz) {
+  for (int r = 0; r < height; r++)
+    for (int c = 0; c < width; c++) {
+      const size_t o = (size_t)r * width + c;
+      float d = (float)(disp[o] / 16.0f);
+      pt3 p = {NAN, NAN, NAN};
+      if (d > 0) {
+        p = project_disparity((float)(c * scale), (float)(r * scale), d, m);
+        if (finite3(p)) {
+          if (apply_local && m->has_local) p = transform_point(p, m->local);
+        } else {
+          p.x = p.y = p.z = NAN;
+        }
+      }
+      xyz[3 * o] = p.x; xyz[3 * o + 1] = p.y; xyz[3 * o + 2] = p.z;
+    }
+}
+
+/* generateKeypoints3DStereo, dense-map branch, src/slam/src/core/Stereo.cpp:53-117 */
+void sbmo_keypoints3d(const int16_t* disp, int width, int height, const float* kpts, int nk, const sbm_stereo_model* m,
+                      float min_depth, float max_depth, float* xyz) {
+  for (int i = 0; i < nk; i++) {
+    pt3 pt = {NAN, NAN, NAN};
+    const float kx = kpts[2 * i], ky = kpts[2 * i + 1];
+    const int ix = (int)kx, iy = (int)ky;
+    if (ix >= 0 && ix < width && iy >= 0 && iy < height) {
+      short tmps = disp[(size_t)iy * width + ix];
+      float disparity = (float)(tmps / 16.0f);
+      if (disparity < 0) disparity = 0;
+      if (disparity != 0.0f) {
+        pt3 t = project_disparity(kx, ky, disparity, m);
+        if (finite3(t) && (min_depth < 0.0f || t.z > min_depth) && (max_depth <= 0.0f || t.z <= max_depth)) {
+          pt = t;
+          if (m->has_local) pt = transform_point(pt, m->local);
+        }
+      }
+    }
+    xyz[3 * i] = pt.x; xyz[3 * i + 1] = pt.y; xyz[3 * i + 2] = pt.z;
+  }
 }

@@ -79,6 +79,15 @@ int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const
 int sbmo_compute_batch(const sbm_params* p, int n, const uint8_t* left, const uint8_t* right, int width, int height,
                        int16_t* disp, int threads);
 
+/* Consumers of the map, restated from the reference's own C++:
+ * SensorData.cpp:50-58 (decimation), Stereo.cpp:157-199 (projectDisparityTo3D / isFinite / transformPoint),
+ * main.cpp:522-553 (reprojection of the decimated map), Stereo.cpp:53-117 (keypoints, dense-map branch). */
+void sbmo_decimate(const int16_t* disp, int width, int height, int scale, int16_t* out);
+void sbmo_reproject(const int16_t* disp, int width, int height, int scale, const sbm_stereo_model* m, int apply_local,
+                    float* xyz);
+void sbmo_keypoints3d(const int16_t* disp, int width, int height, const float* kpts, int nk, const sbm_stereo_model* m,
+                      float min_depth, float max_depth, float* xyz);
+
 int sbmo_max_threads(void);
 
 #ifdef __cplusplus

@@ -35,6 +35,24 @@ class SbmParams(ctypes.Structure):
     ]
 
 
+class StereoModel(ctypes.Structure):
+    """Mirror of `sbm_stereo_model` (include/sbm.h)."""
+
+    _fields_ = [(k, ctypes.c_double) for k in ("fx_l", "fy_l", "cx_l", "cy_l", "Tx_l", "fx_r", "fy_r", "cx_r", "Tx_r")] + [
+        ("local", ctypes.c_float * 12), ("has_local", ctypes.c_int32)]
+
+
+def make_model(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, baseline=0.537, cx_r=None, local=None):
+    """KITTI-like rectified pair: P0 = [f 0 cx 0; ...], P1 = [f 0 cx -f*b; ...]."""
+    m = StereoModel()
+    m.fx_l, m.fy_l, m.cx_l, m.cy_l, m.Tx_l = fx, fy, cx, cy, 0.0
+    m.fx_r, m.fy_r, m.cx_r, m.Tx_r = fx, fy, cx if cx_r is None else cx_r, -fx * baseline
+    if local is not None:
+        m.local[:] = [float(v) for v in local]
+        m.has_local = 1
+    return m
+
+
 def make_params(num_disparities=64, block_size=21, prefilter_cap=31, min_disparity=0, texture_threshold=10,
                 uniqueness_ratio=15, speckle_window_size=0, speckle_range=0, disp12_max_diff=-1,
                 prefilter_type=1, prefilter_size=9, roi1=(0, 0, 0, 0), roi2=(0, 0, 0, 0)):
@@ -87,6 +105,14 @@ def lib():
         L.sbmo_compute_batch.argtypes = [pp, ci, u8p, u8p, ci, ci, i16p, ci]
         L.sbmo_compute_batch.restype = ci
         L.sbmo_max_threads.restype = ci
+        f32p = ctypes.POINTER(ctypes.c_float)
+        mp = ctypes.POINTER(StereoModel)
+        L.sbmo_decimate.argtypes = [i16p, ci, ci, ci, i16p]
+        L.sbmo_decimate.restype = None
+        L.sbmo_reproject.argtypes = [i16p, ci, ci, ci, mp, ci, f32p]
+        L.sbmo_reproject.restype = None
+        L.sbmo_keypoints3d.argtypes = [i16p, ci, ci, f32p, ci, mp, ctypes.c_float, ctypes.c_float, f32p]
+        L.sbmo_keypoints3d.restype = None
         _LIB = L
     return _LIB
 
@@ -198,3 +224,30 @@ def compute_batch(params, left, right, threads=None):
 
 def max_threads():
     return min(lib().sbmo_max_threads(), os.cpu_count() or 1)
+
+
+def decimate(disp, scale):
+    disp = np.ascontiguousarray(disp, dtype=np.int16)
+    h, w = disp.shape
+    out = np.empty((h // scale, w // scale), np.int16)
+    lib().sbmo_decimate(_p(disp, ctypes.c_int16), w, h, scale, _p(out, ctypes.c_int16))
+    return out
+
+
+def reproject(disp, scale, model, apply_local=True):
+    disp = np.ascontiguousarray(disp, dtype=np.int16)
+    h, w = disp.shape
+    xyz = np.empty((h, w, 3), np.float32)
+    lib().sbmo_reproject(_p(disp, ctypes.c_int16), w, h, scale, ctypes.byref(model), 1 if apply_local else 0,
+                         _p(xyz, ctypes.c_float))
+    return xyz
+
+
+def keypoints3d(disp, kpts, model, min_depth=0.0, max_depth=0.0):
+    disp = np.ascontiguousarray(disp, dtype=np.int16)
+    kpts = np.ascontiguousarray(kpts, dtype=np.float32)
+    h, w = disp.shape
+    xyz = np.empty((len(kpts), 3), np.float32)
+    lib().sbmo_keypoints3d(_p(disp, ctypes.c_int16), w, h, _p(kpts, ctypes.c_float), len(kpts), ctypes.byref(model),
+                           min_depth, max_depth, _p(xyz, ctypes.c_float))
+    return xyz

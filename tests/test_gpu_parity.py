@@ -257,3 +257,46 @@ def test_idempotent_and_deterministic(torch_cuda, pkg):
     assert np.array_equal(a, b)
     for i in range(2, 8):
         assert np.array_equal(a[i], a[i % 2])
+
+
+def _same_floats(a, b):
+    """bit-identical float32 arrays (NaN payloads aside: NaN must be at the same places)."""
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32))
+
+
+def test_map_consumers_bit_exact(torch_cuda, pkg, oracle):
+    """decimation (SensorData.cpp:50-58), reprojection (Stereo.cpp:157-199, main.cpp:522-553) and
+    keypoint depth (Stereo.cpp:53-117) on the device vs the restatement of the reference's own C++ expressions.
+    Floating point: tolerance 0 (same operation order and types, no FMA contraction)."""
+    torch = torch_cuda
+    from u96_slam_amd import synth
+
+    L, R = synth.make_batch(0, 2, 1242, 375, 128)
+    bm = pkg.StereoBM.create(128, 15)
+    bm.setDisp12MaxDiff(1)
+    bm.setSpeckleWindowSize(50)
+    bm.setSpeckleRange(32)
+    disp = bm.compute(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+    hd = disp.cpu().numpy()
+    local = [0, 0, 1, 0.1, -1, 0, 0, 0.2, 0, -1, 0, 0.3]
+    for mk in (dict(), dict(cx_r=600.5, local=local)):
+        mo = oracle.make_model(**mk)
+        mg = pkg.StereoModel()
+        import ctypes
+        ctypes.memmove(ctypes.byref(mg), ctypes.byref(mo), ctypes.sizeof(mg))
+        dec = bm.decimate(disp, 4)
+        assert dec.shape == (2, 93, 310)
+        for i in range(2):
+            assert np.array_equal(dec[i].cpu().numpy(), oracle.decimate(hd[i], 4))
+        xyz = bm.reproject(dec, mg, scale=4).cpu().numpy()
+        full = bm.reproject(disp[0], mg, scale=1, apply_local=False).cpu().numpy()
+        for i in range(2):
+            assert _same_floats(xyz[i], oracle.reproject(dec[i].cpu().numpy(), 4, mo))
+        assert _same_floats(full, oracle.reproject(hd[0], 1, mo, apply_local=False))
+        assert np.isfinite(full[..., 2]).mean() > 0.3 and np.nanmin(full[..., 2]) > 0
+        rng = np.random.default_rng(4)
+        kp = np.stack([rng.uniform(-3, 1245, 500), rng.uniform(-3, 378, 500)], 1).astype(np.float32)
+        for mind, maxd in ((0.0, 0.0), (2.0, 30.0), (-1.0, 8.0)):
+            got = bm.keypoints3d(disp[1], torch.from_numpy(kp).cuda(), mg, mind, maxd).cpu().numpy()
+            assert _same_floats(got, oracle.keypoints3d(hd[1], kp, mo, mind, maxd))

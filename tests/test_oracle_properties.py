@@ -199,3 +199,42 @@ def test_batch_matches_single(oracle):
     got = oracle.compute_batch(p, np.stack(Ls), np.stack(Rs), threads=2)
     for i in range(3):
         assert np.array_equal(got[i], oracle.compute(p, Ls[i], Rs[i]))
+
+
+def test_map_consumers_match_numpy_restatement(oracle):
+    """Oracle functions for SURVEY 8f rank 1 against an independent numpy emulation of the reference's expressions
+    (Stereo.cpp:157-199, SensorData.cpp:50-58): float where the C++ is float, double where it is double."""
+    rng = np.random.default_rng(1)
+    d = rng.integers(-16, 2000, (50, 80)).astype(np.int16)
+    local = [0, 0, 1, 0.1, -1, 0, 0, 0.2, 0, -1, 0, 0.3]
+    for mk in (dict(), dict(cx_r=600.5, local=local)):
+        m = oracle.make_model(**mk)
+        assert np.array_equal(oracle.decimate(d, 4), d[::4, ::4][:12, :20])
+
+        def proj(px, py, disp):
+            c = np.float32(m.cx_r - m.cx_l)
+            dc = np.float32(np.float32(disp) + c)
+            wx = np.float32((m.Tx_l / m.fx_l - m.Tx_r / m.fx_r) / np.float64(dc))
+            wy = np.float32((m.Tx_l / m.fy_l - m.Tx_r / m.fy_r) / np.float64(dc))
+            p = np.array([np.float32((np.float64(px) - m.cx_l) * np.float64(wx)),
+                          np.float32((np.float64(py) - m.cy_l) * np.float64(wy)), np.float32(m.fx_l * np.float64(wx))], np.float32)
+            if m.has_local:
+                t = np.array(list(m.local), np.float32).reshape(3, 4)
+                p = np.array([np.float32(np.float32(np.float32(t[r, 0] * p[0]) + np.float32(t[r, 1] * p[1])) + np.float32(t[r, 2] * p[2])) + t[r, 3]
+                              for r in range(3)], np.float32)
+            return p
+
+        full = oracle.reproject(d, 4, m)
+        with np.errstate(all="ignore"):
+            for y in range(0, 50, 7):
+                for x in range(0, 80, 3):
+                    dd = np.float32(d[y, x]) / np.float32(16)
+                    if dd > 0:
+                        e = proj(np.float32(4 * x), np.float32(4 * y), dd)
+                        assert np.isfinite(e).all()
+                        assert np.array_equal(e.view(np.uint32), full[y, x].view(np.uint32)), (x, y)
+                    else:
+                        assert np.isnan(full[y, x]).all()
+        kp = np.array([[10.7, 7.2], [79.9, 49.9], [-1, 3], [5, 50]], np.float32)
+        k3 = oracle.keypoints3d(d, kp, m, 0.0, 0.0)
+        assert np.isnan(k3[2]).all() and np.isnan(k3[3]).all()

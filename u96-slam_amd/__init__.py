@@ -10,8 +10,8 @@ Layout
 There is no CPU fallback in this package: constructing a StereoBM without the built HIP library or without a
 GPU raises. The CPU oracle lives in /oracle and is only used by the tests and by bench.py's cpu_baseline leg.
 """
-from .stereobm import (StereoBM, StereoBMError, SbmParams, library_path, load_library, PREFILTER_XSOBEL,  # noqa: F401
+from .stereobm import (StereoBM, StereoBMError, SbmParams, StereoModel, library_path, load_library, PREFILTER_XSOBEL,  # noqa: F401
                        PREFILTER_NORMALIZED_RESPONSE)
 
-__all__ = ["StereoBM", "StereoBMError", "SbmParams", "library_path", "load_library", "PREFILTER_XSOBEL",
+__all__ = ["StereoBM", "StereoBMError", "SbmParams", "StereoModel", "library_path", "load_library", "PREFILTER_XSOBEL",
            "PREFILTER_NORMALIZED_RESPONSE"]

@@ -331,6 +331,38 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   return SBM_OK;
 }
 
+int sbm_decimate_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale, void* d_out, int sync) {
+  if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  if (width <= 0 || height <= 0 || scale <= 0) return SBM_ERR_SIZE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_decimate((const int16_t*)d_disp, (int16_t*)d_out, n, width, height, scale, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_reproject_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale,
+                         const sbm_stereo_model* model, int apply_local, void* d_xyz, int sync) {
+  if (!h || !d_disp || !d_xyz || !model) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  if (width <= 0 || height <= 0 || scale <= 0) return SBM_ERR_SIZE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_reproject((const int16_t*)d_disp, (float*)d_xyz, n, width, height, scale, *model, apply_local, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_keypoints3d_device(sbm_handle* h, const void* d_disp, int width, int height, const void* d_kpts, int nk,
+                           const sbm_stereo_model* model, float min_depth, float max_depth, void* d_xyz, int sync) {
+  if (!h || !d_disp || !model || (nk > 0 && (!d_kpts || !d_xyz))) return SBM_ERR_NULL;
+  if (width <= 0 || height <= 0 || nk < 0) return SBM_ERR_SIZE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_keypoints3d((const int16_t*)d_disp, (const float*)d_kpts, (float*)d_xyz, width, height, nk, *model,
+                               min_depth, max_depth, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms) {
   if (!h || !name || !ms) return SBM_ERR_NULL;
   HIPCHK(h, hipSetDevice(h->device));

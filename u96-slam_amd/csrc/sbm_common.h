@@ -56,4 +56,11 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
                           hipStream_t s);
 
+// Consumers of the map (sbm_consume.hip): decimation, reprojection, keypoint depth.
+hipError_t launch_decimate(const int16_t* disp, int16_t* out, int n, int W, int H, int scale, hipStream_t s);
+hipError_t launch_reproject(const int16_t* disp, float* xyz, int n, int W, int H, int scale, const sbm_stereo_model& m,
+                            int apply_local, hipStream_t s);
+hipError_t launch_keypoints3d(const int16_t* disp, const float* kp, float* xyz, int W, int H, int nk,
+                              const sbm_stereo_model& m, float min_depth, float max_depth, hipStream_t s);
+
 }  // namespace sbm

@@ -33,6 +33,14 @@ class SbmParams(ctypes.Structure):
     ]
 
 
+class StereoModel(ctypes.Structure):
+    """`sbm_stereo_model` of include/sbm.h: the StereoCameraModel entries the reference's reprojection reads
+    (include/core/StereoCameraModel.h:25-34) plus the optional local transform."""
+
+    _fields_ = [(k, ctypes.c_double) for k in ("fx_l", "fy_l", "cx_l", "cy_l", "Tx_l", "fx_r", "fy_r", "cx_r", "Tx_r")] + [
+        ("local", ctypes.c_float * 12), ("has_local", ctypes.c_int32)]
+
+
 class StereoBMError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"sbm status {code}: {message}")
@@ -76,6 +84,10 @@ def load_library():
     L.sbm_debug_fetch.argtypes = [vp, ci, vp, sz]
     L.sbm_set_profiling.argtypes = [vp, ci]
     L.sbm_get_profile.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
+    mp = ctypes.POINTER(StereoModel)
+    L.sbm_decimate_device.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci]
+    L.sbm_reproject_device.argtypes = [vp, ci, vp, ci, ci, ci, mp, ci, vp, ci]
+    L.sbm_keypoints3d_device.argtypes = [vp, vp, ci, ci, vp, ci, mp, ctypes.c_float, ctypes.c_float, vp, ci]
     L.sbm_stream.argtypes = [vp]
     L.sbm_stream.restype = vp
     L.sbm_strerror.argtypes = [ci]
@@ -221,6 +233,45 @@ class StereoBM:
     def launch_raw(self, n, d_left, d_right, w, h, d_disp, sync=False):
         """Thin call of sbm_compute_device on raw device addresses (used by bench.py's timed loop)."""
         _check(self._L.sbm_compute_device(self._h, n, d_left, d_right, w, h, d_disp, 1 if sync else 0), self._h)
+
+    # ---- consumers of the map (SensorData.cpp:50-58, Stereo.cpp:53-117,157-199, main.cpp:522-553) ----------------
+    def decimate(self, disp, scale=4):
+        """torch CUDA int16 (n,H,W) or (H,W) -> every scale-th pixel, on the device."""
+        import torch
+
+        d3 = disp if disp.dim() == 3 else disp[None]
+        d3 = d3.contiguous()
+        n, h, w = d3.shape
+        out = torch.empty((n, h // scale, w // scale), dtype=torch.int16, device=d3.device)
+        torch.cuda.current_stream(d3.device).synchronize()
+        _check(self._L.sbm_decimate_device(self._h, n, d3.data_ptr(), w, h, scale, out.data_ptr(), 1), self._h)
+        return out if disp.dim() == 3 else out[0]
+
+    def reproject(self, disp, model, scale=1, apply_local=True):
+        """torch CUDA int16 map(s) -> float32 (..., H, W, 3) points, NaN where invalid."""
+        import torch
+
+        d3 = disp if disp.dim() == 3 else disp[None]
+        d3 = d3.contiguous()
+        n, h, w = d3.shape
+        xyz = torch.empty((n, h, w, 3), dtype=torch.float32, device=d3.device)
+        torch.cuda.current_stream(d3.device).synchronize()
+        _check(self._L.sbm_reproject_device(self._h, n, d3.data_ptr(), w, h, scale, ctypes.byref(model),
+                                            1 if apply_local else 0, xyz.data_ptr(), 1), self._h)
+        return xyz if disp.dim() == 3 else xyz[0]
+
+    def keypoints3d(self, disp, kpts, model, min_depth=0.0, max_depth=0.0):
+        """One full-resolution torch CUDA int16 map + float32 (nk,2) keypoints (x,y) -> float32 (nk,3)."""
+        import torch
+
+        disp = disp.contiguous()
+        kpts = kpts.contiguous()
+        h, w = disp.shape
+        xyz = torch.empty((kpts.shape[0], 3), dtype=torch.float32, device=disp.device)
+        torch.cuda.current_stream(disp.device).synchronize()
+        _check(self._L.sbm_keypoints3d_device(self._h, disp.data_ptr(), w, h, kpts.data_ptr(), kpts.shape[0],
+                                              ctypes.byref(model), min_depth, max_depth, xyz.data_ptr(), 1), self._h)
+        return xyz
 
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
