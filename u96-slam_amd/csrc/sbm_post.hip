@@ -140,10 +140,8 @@ __device__ __forceinline__ int uf_root_final(const int* L, int i) {
 struct RowWalk {
   int prev_last, carry;
   __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; }
-  __device__ __forceinline__ void step(const int16_t* d, int cb, int W, int lane, int newval, int maxdiff, int& v,
-                                       bool& valid, bool& head, int& start) {
-    const int x = cb + lane;
-    v = x < W ? (int)d[x] : newval;
+  __device__ __forceinline__ void step(int v, int cb, int lane, int newval, int maxdiff, bool& valid, bool& head,
+                                       int& start) {
     int pv = __shfl_up(v, 1, 64);
     if (lane == 0) pv = prev_last;
     valid = v != newval;
@@ -154,6 +152,17 @@ struct RowWalk {
     prev_last = __shfl(v, 63, 64);
   }
 };
+
+// Rows are walked in groups of SPK_G chunks whose values are loaded up front (SPK_G independent loads in flight per
+// lane) -- the walk itself is a serial chain of ballots, so without this every chunk would pay a full memory latency.
+constexpr int SPK_G = 8;
+__device__ __forceinline__ void spk_load_group(const int16_t* d, int cb0, int W, int lane, int newval, int (&v)[SPK_G]) {
+#pragma unroll
+  for (int g = 0; g < SPK_G; g++) {
+    const int x = cb0 + 64 * g + lane;
+    v[g] = x < W ? (int)d[x] : newval;
+  }
+}
 
 #define SPK_ROW_SETUP                                          \
   const int lane = threadIdx.x & 63;                           \
@@ -172,21 +181,32 @@ __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __rest
   int* C = counts + plane_off;
   // right to left: every head learns the distance to the next boundary (head or invalid pixel or row end)
   int next_b = W;
-  for (int cb = ((W - 1) / 64) * 64; cb >= 0; cb -= 64) {
-    const int x = cb + lane;
-    const int v = x < W ? (int)d[x] : newval;
-    int pv = __shfl_up(v, 1, 64);
-    if (lane == 0) pv = cb > 0 ? (int)d[cb - 1] : newval;
-    const bool valid = v != newval;
-    const bool head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
-    const unsigned long long bm = __ballot(!valid || head);  // lanes beyond W count as invalid = boundary
-    const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
-    const int nb = above ? x + __ffsll((long long)above) : next_b;
-    if (head) {
-      L[y * W + x] = y * W + x;
-      C[y * W + x] = nb - x;
+  const int ngroups = (W + 64 * SPK_G - 1) / (64 * SPK_G);
+  for (int gi = ngroups - 1; gi >= 0; gi--) {
+    const int cb0 = gi * 64 * SPK_G;
+    int vs[SPK_G];
+    spk_load_group(d, cb0, W, lane, newval, vs);
+    const int left_of_group = cb0 > 0 ? (int)d[cb0 - 1] : newval;
+#pragma unroll
+    for (int g = SPK_G - 1; g >= 0; g--) {
+      const int cb = cb0 + 64 * g;
+      if (cb >= W) continue;
+      const int x = cb + lane;
+      const int v = vs[g];
+      int pv = __shfl_up(v, 1, 64);
+      const int left = g > 0 ? __shfl(vs[g > 0 ? g - 1 : 0], 63, 64) : left_of_group;
+      if (lane == 0) pv = left;
+      const bool valid = v != newval;
+      const bool head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
+      const unsigned long long bm = __ballot(!valid || head);  // lanes beyond W count as invalid = boundary
+      const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
+      const int nb = above ? x + __ffsll((long long)above) : next_b;
+      if (head) {
+        L[y * W + x] = y * W + x;
+        C[y * W + x] = nb - x;
+      }
+      if (bm) next_b = cb + __ffsll((long long)bm) - 1;
     }
-    if (bm) next_b = cb + __ffsll((long long)bm) - 1;
   }
 }
 
@@ -201,17 +221,26 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
   up.init(newval);
   dn.init(newval);
   bool prev_cd = false;  // vertical contact at the pixel left of the chunk
-  for (int cb = 0; cb < W; cb += 64) {
-    int vu, vd, su, sd;
-    bool valu, vald, hu, hd;
-    up.step(du, cb, W, lane, newval, maxdiff, vu, valu, hu, su);
-    dn.step(dd, cb, W, lane, newval, maxdiff, vd, vald, hd, sd);
-    const bool cd = valu && vald && abs(vu - vd) <= maxdiff;
-    bool pcd = __shfl_up((int)cd, 1, 64) != 0;
-    if (lane == 0) pcd = prev_cd;
-    // same two runs as the pixel to the left and that pixel already made the contact -> nothing new
-    if (cd && !(pcd && !hu && !hd)) uf_union(L, y * W + su, (y + 1) * W + sd);
-    prev_cd = __shfl((int)cd, 63, 64) != 0;
+  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
+    int vus[SPK_G], vds[SPK_G];
+    spk_load_group(du, cb0, W, lane, newval, vus);
+    spk_load_group(dd, cb0, W, lane, newval, vds);
+#pragma unroll
+    for (int g = 0; g < SPK_G; g++) {
+      const int cb = cb0 + 64 * g;
+      if (cb >= W) break;
+      const int vu = vus[g], vd = vds[g];
+      int su, sd;
+      bool valu, vald, hu, hd;
+      up.step(vu, cb, lane, newval, maxdiff, valu, hu, su);
+      dn.step(vd, cb, lane, newval, maxdiff, vald, hd, sd);
+      const bool cd = valu && vald && abs(vu - vd) <= maxdiff;
+      bool pcd = __shfl_up((int)cd, 1, 64) != 0;
+      if (lane == 0) pcd = prev_cd;
+      // same two runs as the pixel to the left and that pixel already made the contact -> nothing new
+      if (cd && !(pcd && !hu && !hd)) uf_union(L, y * W + su, (y + 1) * W + sd);
+      prev_cd = __shfl((int)cd, 63, 64) != 0;
+    }
   }
 }
 
@@ -225,15 +254,22 @@ __global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __res
   int* C = counts + plane_off;
   RowWalk rw;
   rw.init(newval);
-  for (int cb = 0; cb < W; cb += 64) {
-    int v, st;
-    bool valid, head;
-    rw.step(d, cb, W, lane, newval, maxdiff, v, valid, head, st);
-    if (head) {
-      const int self = y * W + cb + lane;
-      const int r = uf_root_final(L, self);
-      if (r != self && __hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize)
-        atomicAdd(C + r, C[self]);
+  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
+    int vs[SPK_G];
+    spk_load_group(d, cb0, W, lane, newval, vs);
+#pragma unroll
+    for (int g = 0; g < SPK_G; g++) {
+      const int cb = cb0 + 64 * g;
+      if (cb >= W) break;
+      int st;
+      bool valid, head;
+      rw.step(vs[g], cb, lane, newval, maxdiff, valid, head, st);
+      if (head) {
+        const int self = y * W + cb + lane;
+        const int r = uf_root_final(L, self);
+        if (r != self && __hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize)
+          atomicAdd(C + r, C[self]);
+      }
     }
   }
 }
@@ -249,16 +285,23 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
   RowWalk rw;
   rw.init(newval);
   int carry_kill = 0;  // decision of the run that contains the pixel left of the chunk
-  for (int cb = 0; cb < W; cb += 64) {
-    int v, st;
-    bool valid, head;
-    rw.step(d, cb, W, lane, newval, maxdiff, v, valid, head, st);
-    int kill = 0;
-    if (head) kill = C[uf_root_final(L, y * W + cb + lane)] <= maxsize;
-    const int from = __shfl(kill, st >= cb ? st - cb : 0, 64);   // decision of this lane's run head (if in the chunk)
-    const int mine = valid ? (st >= cb ? from : carry_kill) : 0;
-    if (mine) d[cb + lane] = (int16_t)newval;   // rw keeps the ORIGINAL value of the chunk's last pixel for the next chunk
-    carry_kill = __shfl(mine, 63, 64);
+  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
+    int vs[SPK_G];
+    spk_load_group(d, cb0, W, lane, newval, vs);   // original values: the stores below never feed a later load
+#pragma unroll
+    for (int g = 0; g < SPK_G; g++) {
+      const int cb = cb0 + 64 * g;
+      if (cb >= W) break;
+      int st;
+      bool valid, head;
+      rw.step(vs[g], cb, lane, newval, maxdiff, valid, head, st);
+      int kill = 0;
+      if (head) kill = C[uf_root_final(L, y * W + cb + lane)] <= maxsize;
+      const int from = __shfl(kill, st >= cb ? st - cb : 0, 64);   // decision of this lane's run head (if in the chunk)
+      const int mine = valid ? (st >= cb ? from : carry_kill) : 0;
+      if (mine) d[cb + lane] = (int16_t)newval;
+      carry_kill = __shfl(mine, 63, 64);
+    }
   }
 }
 
