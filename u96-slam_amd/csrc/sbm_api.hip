@@ -19,6 +19,8 @@ struct sbm_handle {
   sbm_params p;
   int device;
   hipStream_t stream;
+  hipStream_t stream2;   // side stream: the latency-bound border kernel overlaps the VALU-bound SAD kernel
+  hipEvent_t ev_fork, ev_join;
   int last_hip;
   // scratch, sized for (cap_n, cap_W, cap_H, cap pitch)
   int cap_n, cap_W, cap_H, cap_pitch;
@@ -133,6 +135,17 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
     delete h;
     return SBM_ERR_NO_DEVICE;
   }
+  {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipStreamDestroy(h->stream);
+      delete h;
+      return SBM_ERR_HIP;
+    }
+  }
   h->ev_ok = true;
   for (int r = 0; r < sbm_handle::kRing; r++)
     for (int i = 0; i < sbm_handle::kMarks; i++) h->ev_ok &= hipEventCreate(&h->ev[r][i]) == hipSuccess;
@@ -148,6 +161,10 @@ void sbm_destroy(sbm_handle* h) {
   free_staging(h);
   for (int r = 0; r < sbm_handle::kRing; r++)
     for (int i = 0; i < sbm_handle::kMarks; i++) hipEventDestroy(h->ev[r][i]);
+  hipStreamSynchronize(h->stream2);
+  hipEventDestroy(h->ev_fork);
+  hipEventDestroy(h->ev_join);
+  hipStreamDestroy(h->stream2);
   hipStreamDestroy(h->stream);
   delete h;
 }
@@ -300,23 +317,34 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
       g.cost16 = sad_fast_supported(g) && g.xend - (xhi - g.w2 + 1) == g.w2;
       h->last = g;
     }
-    if (sad_fast_supported(g)) {
-      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &fa, &fb, h->stream));
+    const bool fast = sad_fast_supported(g);
+    if (fast) {
+      const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
+      fa = g.w2; fb = xhi - g.w2 + 1;   // the interior range launch_sad_fast will cover
     }
-    mark(h, 2);
     // columns left and right of the fast range: clamped windows (or everything when the fast path is off).
     // They only matter if they can influence the output: through the LR check or when inside the valid ROI.
     const bool borders_visible = g.want_cost || g.col0 < g.lofs + fa || g.col1 > g.lofs + fb;
-    if (fb <= fa) {
-      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
-    } else if (borders_visible) {
+    const bool side = fast && borders_visible;   // border columns on the side stream, concurrently with the interior
+    if (side) {
+      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
       if (fa == g.w2 && g.xend - fb == g.w2) {
-        HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream));
+        HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream2));
       } else {
-        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, fa, h->stream));
-        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fb, g.xend, h->stream));
+        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, fa, h->stream2));
+        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fb, g.xend, h->stream2));
       }
+      HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
     }
+    if (fast) {
+      int xa = 0, xb = 0;
+      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
+    } else {
+      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
+    }
+    mark(h, 2);
+    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
   } else {
     mark(h, 2);
   }

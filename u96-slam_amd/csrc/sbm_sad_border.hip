@@ -199,7 +199,10 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   const int rows = g.row1 - g.row0;
   // short segments: each row costs a latency-bound staging round trip, so favour many concurrent workgroups
   static const int seg_rows_env = [] { const char* e = getenv("SBM_BORDER_SEG"); return e ? atoi(e) : 0; }();
-  const int seg_rows = seg_rows_env > 0 ? seg_rows_env : 12;  // measured optimum 10..16 rows (KITTI w15, 640x480 w21)
+  // The kernel runs on a side stream concurrently with the interior kernel. Short segments keep its critical path
+  // (rows x ~per-row latency) below the interior kernel's duration; longer ones would save priming work (w-1 rows per
+  // segment) but make it the tail. Measured: 12-24 rows is the flat optimum on KITTI w15 and 640x480 w21.
+  const int seg_rows = seg_rows_env > 0 ? seg_rows_env : 16;
   int nseg = std::max(1, rows / seg_rows);
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
