@@ -34,17 +34,19 @@ __device__ __forceinline__ void vsum4(uint32_t a, uint32_t b, uint32_t c, uint32
   odd = ((a >> 8) & m) + 2u * ((b >> 8) & m) + ((c >> 8) & m);
 }
 
-// grid: x = ceil(W/16/64), y = ceil(H/4), z = 2*n (image index: even = left, odd = right); 16 pixels per thread
+// grid: x = ceil(H*ceil(W/16)/256), y = 2*n (image index: even = left, odd = right); 16 pixels per thread
 __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                         uint8_t* __restrict__ pf_l, uint8_t* __restrict__ pf_r, int W, int H,
                                                         int pitch, int padl, int plane, int cap) {
-  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 16;
-  if (x0 >= W) return;
-  const int y = blockIdx.y * 4 + threadIdx.y;   // 4 rows per workgroup (fewer, fatter workgroups: dispatch-rate bound otherwise)
-  if (y >= H) return;
-  const int img = blockIdx.z >> 1;
-  const uint8_t* src = ((blockIdx.z & 1) ? right : left) + (size_t)img * W * H;
-  uint8_t* dst = ((blockIdx.z & 1) ? pf_r : pf_l) + (size_t)img * plane + (size_t)y * pitch + padl + x0;
+  // threads are flattened over (row, 16-pixel piece) of one image so that every lane has work whatever the width
+  const int npiece = (W + 15) / 16;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= npiece * H) return;
+  const int y = t / npiece;
+  const int x0 = (t - y * npiece) * 16;
+  const int img = blockIdx.y >> 1;
+  const uint8_t* src = ((blockIdx.y & 1) ? right : left) + (size_t)img * W * H;
+  uint8_t* dst = ((blockIdx.y & 1) ? pf_r : pf_l) + (size_t)img * plane + (size_t)y * pitch + padl + x0;
 
   uint32_t out[4];
   if ((H & 1) && y == H - 1) {
@@ -100,8 +102,9 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
 
 hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
                             const Geom& g, hipStream_t s) {
-  dim3 grid((g.W + 1023) / 1024, (g.H + 3) / 4, 2 * g.n);
-  hipLaunchKernelGGL(prefilter_kernel, grid, dim3(64, 4), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl,
+  const int npiece = (g.W + 15) / 16;
+  dim3 grid((npiece * g.H + 255) / 256, 2 * g.n);
+  hipLaunchKernelGGL(prefilter_kernel, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl,
                      g.plane, g.cap);
   return hipGetLastError();
 }

@@ -100,8 +100,10 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
 #pragma unroll
       for (int v = 0; v < NVC; v++) {
         const int ov = a.rofs + clampi(xfirst + v, -a.rofs, a.W - a.rofs - a.nd) - rb0;
-        const int t = (int)Lbuf[par][which][v] - (int)Rbuf[par][which][ov + d];
-        C[v] += sign * (t < 0 ? -t : t);
+        // v_sad_u8 on zero-extended bytes: |l - r| + accumulator in one instruction
+        const unsigned l = Lbuf[par][which][v], r = Rbuf[par][which][ov + d];
+        if (sign > 0) C[v] = (int)__builtin_amdgcn_sad_u8(l, r, (unsigned)C[v]);
+        else C[v] -= (int)__builtin_amdgcn_sad_u8(l, r, 0u);
       }
     }
     if (tid < NVC) {
