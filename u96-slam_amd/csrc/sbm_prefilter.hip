@@ -34,76 +34,97 @@ __device__ __forceinline__ void vsum4(uint32_t a, uint32_t b, uint32_t c, uint32
   odd = ((a >> 8) & m) + 2u * ((b >> 8) & m) + ((c >> 8) & m);
 }
 
-// grid: x = ceil(H*ceil(W/16)/256), y = 2*n (image index: even = left, odd = right); 16 pixels per thread
+// Each thread produces a 16-pixel x PF_ROWS-row tile: PF_ROWS + 2 source row pieces are loaded once and every
+// vertical 1-2-1 sum reuses them (1.5 loads per output row instead of 3).
+constexpr int PF_ROWS = 4;
+
+// grid: x = ceil(ceil(H/PF_ROWS)*ceil(W/16)/256), y = 2*n (image index: even = left, odd = right)
 __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                         uint8_t* __restrict__ pf_l, uint8_t* __restrict__ pf_r, int W, int H,
                                                         int pitch, int padl, int plane, int cap) {
-  // threads are flattened over (row, 16-pixel piece) of one image so that every lane has work whatever the width
+  // threads are flattened over (row group, 16-pixel piece) of one image so that every lane has work whatever the width
   const int npiece = (W + 15) / 16;
+  const int ngroup = (H + PF_ROWS - 1) / PF_ROWS;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= npiece * H) return;
-  const int y = t / npiece;
-  const int x0 = (t - y * npiece) * 16;
+  if (t >= npiece * ngroup) return;
+  const int yg = t / npiece;
+  const int y0 = yg * PF_ROWS;
+  const int x0 = (t - yg * npiece) * 16;
   const int img = blockIdx.y >> 1;
   const uint8_t* src = ((blockIdx.y & 1) ? right : left) + (size_t)img * W * H;
-  uint8_t* dst = ((blockIdx.y & 1) ? pf_r : pf_l) + (size_t)img * plane + (size_t)y * pitch + padl + x0;
+  uint8_t* dst0 = ((blockIdx.y & 1) ? pf_r : pf_l) + (size_t)img * plane + padl + x0;
+  const bool interior = x0 >= 16 && x0 + 32 <= W;
 
-  uint32_t out[4];
-  if ((H & 1) && y == H - 1) {
-    out[0] = out[1] = out[2] = out[3] = (uint32_t)(cap + kPfBias) * 0x01010101u;
-  } else {
-    const int ym = y > 0 ? y - 1 : (H > 1 ? 1 : 0);
-    const int yp = y < H - 1 ? y + 1 : (H > 1 ? H - 2 : 0);
-    const uint8_t* r0 = src + (size_t)ym * W;
-    const uint8_t* r1 = src + (size_t)y * W;
-    const uint8_t* r2 = src + (size_t)yp * W;
-    int s[18];  // vertical 1-2-1 sums of columns x0-1 .. x0+16
-    if (x0 >= 16 && x0 + 32 <= W) {
-      // interior: bytes x0-1 .. x0+18 of each row from one 16-byte and one 4-byte unaligned load
-      const uint4 a = load_u128_ua(r0 + x0 - 1), b = load_u128_ua(r1 + x0 - 1), c = load_u128_ua(r2 + x0 - 1);
-      const uint32_t a4 = load_u32_unaligned(r0 + x0 + 15), b4 = load_u32_unaligned(r1 + x0 + 15),
-                     c4 = load_u32_unaligned(r2 + x0 + 15);
-      const uint32_t aw[5] = {a.x, a.y, a.z, a.w, a4}, bw[5] = {b.x, b.y, b.z, b.w, b4}, cw[5] = {c.x, c.y, c.z, c.w, c4};
+  // packed pieces of source rows y0-1 .. y0+PF_ROWS (reflect-101 at the image border): bytes x0-1 .. x0+18
+  uint32_t rw[PF_ROWS + 2][5];
+#pragma unroll
+  for (int k = 0; k < PF_ROWS + 2; k++) {
+    int yy = y0 - 1 + k;
+    yy = yy < 0 ? (H > 1 ? 1 : 0) : (yy > H - 1 ? (yy == H ? (H > 1 ? H - 2 : 0) : H - 1) : yy);
+    const uint8_t* r = src + (size_t)yy * W;
+    if (interior) {
+      const uint4 a = load_u128_ua(r + x0 - 1);
+      rw[k][0] = a.x; rw[k][1] = a.y; rw[k][2] = a.z; rw[k][3] = a.w;
+      rw[k][4] = load_u32_unaligned(r + x0 + 15);
+    } else {
+#pragma unroll
+      for (int w = 0; w < 5; w++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          int x = x0 - 1 + 4 * w + i;
+          x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);  // value unused where clamped (edge columns are forced to cap)
+          v |= (uint32_t)r[x] << (8 * i);
+        }
+        rw[k][w] = v;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < PF_ROWS; j++) {
+    const int y = y0 + j;
+    if (y >= H) break;
+    uint32_t out[4];
+    if ((H & 1) && y == H - 1) {
+      out[0] = out[1] = out[2] = out[3] = (uint32_t)(cap + kPfBias) * 0x01010101u;
+    } else {
+      int s[18];  // vertical 1-2-1 sums of columns x0-1 .. x0+16
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         uint32_t ev, od;
-        vsum4(aw[k], bw[k], cw[k], ev, od);
+        vsum4(rw[j][k], rw[j + 1][k], rw[j + 2][k], ev, od);
         if (4 * k + 0 < 18) s[4 * k + 0] = (int)(ev & 0xffffu);
         if (4 * k + 1 < 18) s[4 * k + 1] = (int)(od & 0xffffu);
         if (4 * k + 2 < 18) s[4 * k + 2] = (int)(ev >> 16);
         if (4 * k + 3 < 18) s[4 * k + 3] = (int)(od >> 16);
       }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int x = x0 + 4 * k + i;
+          const int v = (x == 0 || x >= W - 1) ? cap : clipcap(s[4 * k + i + 2] - s[4 * k + i], cap);
+          o |= (uint32_t)(v + kPfBias) << (8 * i);
+        }
+        out[k] = o;
+      }
+    }
+    uint8_t* dst = dst0 + (size_t)y * pitch;
+    if (x0 + 16 <= W) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);  // pitch, padl multiples of 16
     } else {
-#pragma unroll
-      for (int i = 0; i < 18; i++) {
-        int x = x0 - 1 + i;
-        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);  // value unused where clamped (edge columns are forced to cap)
-        s[i] = (int)r0[x] + 2 * (int)r1[x] + (int)r2[x];
-      }
+      for (int i = 0; x0 + i < W; i++) dst[i] = (uint8_t)(out[i >> 2] >> (8 * (i & 3)));
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t o = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int x = x0 + 4 * k + i;
-        const int v = (x == 0 || x >= W - 1) ? cap : clipcap(s[4 * k + i + 2] - s[4 * k + i], cap);
-        o |= (uint32_t)(v + kPfBias) << (8 * i);
-      }
-      out[k] = o;
-    }
-  }
-  if (x0 + 16 <= W) {
-    *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);  // pitch, padl multiples of 16
-  } else {
-    for (int i = 0; x0 + i < W; i++) dst[i] = (uint8_t)(out[i >> 2] >> (8 * (i & 3)));
   }
 }
 
 hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
                             const Geom& g, hipStream_t s) {
   const int npiece = (g.W + 15) / 16;
-  dim3 grid((npiece * g.H + 255) / 256, 2 * g.n);
+  const int ngroup = (g.H + PF_ROWS - 1) / PF_ROWS;
+  dim3 grid((npiece * ngroup + 255) / 256, 2 * g.n);
   hipLaunchKernelGGL(prefilter_kernel, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl,
                      g.plane, g.cap);
   return hipGetLastError();
