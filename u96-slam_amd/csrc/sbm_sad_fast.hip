@@ -439,8 +439,10 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
   // segment at ~1/3 of a full row's cost) below ~10 %
   int nseg = 1;
-  const long target = 8192;
+  const long target = 12000;  // measured on KITTI b64: 8-10 segments (11-14k workgroups) is the flat optimum
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
+  static const int nseg_env = [] { const char* e = getenv("SBM_FAST_NSEG"); return e ? atoi(e) : 0; }();
+  if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
   a.strips = strips; a.nseg = nseg; a.npairs = g.n;
