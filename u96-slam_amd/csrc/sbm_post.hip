@@ -80,6 +80,78 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
   }
 }
 
+// Fast variant for the 16-bit cost plane (fast + border SAD kernels) and W <= 256*NPT: the row's disparities and
+// costs are loaded once, up front (NPT independent loads per lane), the row is kept in LDS so the winner's disparity
+// is an LDS read, and the claim key is 32 bits (cost << 16 | x) -> ds_min_u32.
+extern __shared__ __attribute__((aligned(16))) unsigned lr_lds32[];
+
+template <int NPT>
+__global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
+  const int y = blockIdx.x;
+  const size_t base = ((size_t)blockIdx.y * a.H + y) * a.W;
+  int16_t* out = a.disp_out + base;
+  if (y < a.row0 || y >= a.row1) {
+    for (int x = threadIdx.x; x < a.W; x += 256) out[x] = (int16_t)a.filtered;
+    return;
+  }
+  unsigned* keys = lr_lds32;                                             // [W]
+  int16_t* srow = reinterpret_cast<int16_t*>(lr_lds32 + a.W);            // [W] pre-LR disparities of the row
+  const int16_t* dp = a.disp_pre + base;
+  const uint16_t* cp = static_cast<const uint16_t*>(a.cost) + base;
+  const int INV = a.filtered;
+  const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(a.W + min(a.mindisp, 0), a.cx1);
+  int dv[NPT];
+  unsigned cv[NPT];
+#pragma unroll
+  for (int k = 0; k < NPT; k++) {
+    const int x = threadIdx.x + 256 * k;
+    const bool live = x >= a.cx0 && x < a.cx1;
+    dv[k] = live ? (int)dp[x] : INV;
+    cv[k] = (x >= minX1 && x < maxX1) ? (unsigned)cp[x] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < NPT; k++) {
+    const int x = threadIdx.x + 256 * k;
+    if (x < a.W) {
+      keys[x] = 0xffffffffu;
+      srow[x] = (int16_t)dv[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NPT; k++) {
+    const int x = threadIdx.x + 256 * k;
+    const int d = dv[k];
+    if (x >= minX1 && x < maxX1 && d != INV) {
+      const int x2 = x - ((d + 8) >> 4);
+      if (x2 >= 0 && x2 < a.W) atomicMin(&keys[x2], (cv[k] << 16) | (unsigned)x);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NPT; k++) {
+    const int x = threadIdx.x + 256 * k;
+    if (x >= a.W) continue;
+    int d = dv[k];
+    if (x < a.col0 || x >= a.col1) {
+      d = INV;
+    } else if (d != INV && x >= minX1 && x < maxX1) {
+      const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
+      bool bad_a = false, bad_b = false;
+      if (xa >= 0 && xa < a.W) {
+        const unsigned kk = keys[xa];
+        if (kk != 0xffffffffu) bad_a = abs((int)srow[kk & 0xffffu] - d) > a.tol;
+      }
+      if (xb >= 0 && xb < a.W) {
+        const unsigned kk = keys[xb];
+        if (kk != 0xffffffffu) bad_b = abs((int)srow[kk & 0xffffu] - d) > a.tol;
+      }
+      if (bad_a && bad_b) d = INV;
+    }
+    out[x] = (int16_t)d;
+  }
+}
+
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
                           int disp12_max_diff, hipStream_t s) {
   LrArgs a;
@@ -87,6 +159,12 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
   a.W = g.W; a.H = g.H; a.mindisp = g.mindisp; a.nd = g.nd; a.tol = disp12_max_diff * 16; a.filtered = g.filtered;
   a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
   a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;
+  if (a.do_lr && g.cost16 && g.W <= 4096) {
+    const size_t lds16 = (size_t)g.W * 6 + 16;
+    if (g.W <= 2048) hipLaunchKernelGGL(lrcheck16_kernel<8>, dim3(g.H, g.n), dim3(256), lds16, s, a);
+    else hipLaunchKernelGGL(lrcheck16_kernel<16>, dim3(g.H, g.n), dim3(256), lds16, s, a);
+    return hipGetLastError();
+  }
   size_t lds = a.do_lr ? (size_t)g.W * sizeof(unsigned long long) : 0;
   hipLaunchKernelGGL(lrcheck_kernel, dim3(g.H, g.n), dim3(256), lds, s, a);
   return hipGetLastError();
