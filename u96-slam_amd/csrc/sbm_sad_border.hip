@@ -201,10 +201,16 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   const int rows = g.row1 - g.row0;
   // short segments: each row costs a latency-bound staging round trip, so favour many concurrent workgroups
   static const int seg_rows_env = [] { const char* e = getenv("SBM_BORDER_SEG"); return e ? atoi(e) : 0; }();
-  // The kernel runs on a side stream concurrently with the interior kernel. Short segments keep its critical path
-  // (rows x ~per-row latency) below the interior kernel's duration; longer ones would save priming work (w-1 rows per
-  // segment) but make it the tail. Measured: 12-24 rows is the flat optimum on KITTI w15 and 640x480 w21.
-  const int seg_rows = seg_rows_env > 0 ? seg_rows_env : 16;
+  // The kernel runs on a side stream concurrently with the VALU-bound interior kernel, so what it costs is its
+  // instruction total (priming = w-1 extra rows per segment) -- as long as its critical path, (seg + w - 1) row steps
+  // of ~6 us each (two barriers per row), stays inside the interior kernel's duration. Estimate that duration from
+  // the interior kernel's measured rate (~3e12 pixel-disparities/s) and spend 60 % of it.
+  int seg_rows = seg_rows_env;
+  if (seg_rows <= 0) {
+    const double t_interior_us = (double)g.n * g.W * (g.row1 - g.row0) * g.nd / 3.0e12 * 1e6;
+    seg_rows = (int)(0.6 * t_interior_us / 6.0) - (g.wsz - 1);
+    seg_rows = std::max(12, std::min(seg_rows, rows));
+  }
   int nseg = std::max(1, rows / seg_rows);
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
