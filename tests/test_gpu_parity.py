@@ -300,3 +300,29 @@ def test_map_consumers_bit_exact(torch_cuda, pkg, oracle):
         for mind, maxd in ((0.0, 0.0), (2.0, 30.0), (-1.0, 8.0)):
             got = bm.keypoints3d(disp[1], torch.from_numpy(kp).cuda(), mg, mind, maxd).cpu().numpy()
             assert _same_floats(got, oracle.keypoints3d(hd[1], kp, mo, mind, maxd))
+
+
+def test_randomised_parameter_sweep(torch_cuda, pkg, oracle):
+    """Seeded fuzz over the parameter space (fast, border and generic kernels; all post-filter combinations):
+    every stage bit-exact against the oracle."""
+    rng = np.random.default_rng(20261002)
+    for it in range(40):
+        wsz = int(rng.choice([5, 7, 9, 9, 11, 15, 15, 21, 21, 27]))
+        nd = int(rng.choice([16, 32, 48, 64, 96, 128, 160, 256]))
+        mind = int(rng.choice([0, 0, 0, -16, 5, -nd // 2]))
+        h = int(rng.integers(wsz + 8, wsz + 60))
+        w = int(rng.integers(max(nd + abs(mind), 0) + 2 * wsz + 8, max(nd + abs(mind), 0) + 2 * wsz + 220))
+        kw = dict(num_disparities=nd, block_size=wsz, min_disparity=mind, prefilter_cap=int(rng.choice([31, 31, 15, 63, 1])),
+                  texture_threshold=int(rng.choice([0, 10, 10, 200])), uniqueness_ratio=int(rng.choice([0, 5, 10, 15, 40])),
+                  disp12_max_diff=int(rng.choice([-1, 0, 1, 1, 3])))
+        if rng.random() < 0.6:
+            kw.update(speckle_window_size=int(rng.choice([1, 10, 50, 200])), speckle_range=int(rng.choice([0, 4, 16, 32])))
+        L, R = rand_pair(rng, h, w, shift=int(rng.integers(0, 12)), noise=int(rng.integers(0, 6)))
+        if rng.random() < 0.3:   # coarse grey levels: many exact ties
+            L = (L // 64 * 64).astype(np.uint8)
+            R = (R // 64 * 64).astype(np.uint8)
+        eng, ref = run_engine(pkg, oracle, kw, L, R)
+        try:
+            assert_stages_equal(eng, ref, kw)
+        except AssertionError as e:
+            raise AssertionError(f"iteration {it}: {h}x{w} {kw}: {e}")
