@@ -185,6 +185,249 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Second-generation border kernel: the same virtual-column scheme, but a lane owns a disparity QUAD and both sides
+// share one workgroup. One v_mqsad_pk_u16_u8 with the pattern (l,0,0,0) -- the three zero bytes are masked --
+// yields |l - R[k]| for four consecutive right bytes, i.e. four disparities of one virtual column, accumulated into a
+// packed 4 x u16 register pair; the right row piece is staged in LDS as 8-byte entries laid out [p & 3][p >> 2] so
+// that the quads of a wavefront read consecutive entries (conflict-free ds_read_b64). About 3x fewer instructions per
+// row than the per-disparity kernel above (kept as SBM_BORDER_V=1 for A/B and as documentation of the scheme).
+// ---------------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char border_lds[];
+
+template <int W2>
+__global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
+  constexpr int NVC = 3 * W2, WSZ = 2 * W2 + 1;
+  constexpr int RPT = 6;                    // staged 8-byte entries per thread per row: 2*(NVC+nd) <= 6*T (host-checked)
+  typedef unsigned long long u64;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int nq = a.nd >> 2;                 // disparity quads per side
+  const int nsl = (NVC + a.nd) / 4 + 2;     // 8-byte entries per residue class of one staged piece
+  const int npiece = NVC + a.nd;            // entries of one staged piece (entry p = bytes p .. p+7)
+  // ---- LDS carve-up -------------------------------------------------------------------------------------
+  u64* Rb = reinterpret_cast<u64*>(border_lds);                               // [par][which][side][4*nsl]
+  unsigned short* Sb = reinterpret_cast<unsigned short*>(Rb + 2 * 2 * 2 * 4 * nsl);  // [side][W2][nd]
+  unsigned* Kb = reinterpret_cast<unsigned*>(Sb + 2 * W2 * a.nd);             // [side][W2][nq] local best keys
+  int* Tc = reinterpret_cast<int*>(Kb + 2 * W2 * nq);                         // [side][NVC]
+  unsigned* Best = reinterpret_cast<unsigned*>(Tc + 2 * NVC);                 // [side][W2]
+  int* Tsum = reinterpret_cast<int*>(Best + 2 * W2);                          // [side][W2]
+  int* Hit = Tsum + 2 * W2;                                                   // [side][W2]
+  unsigned char* Lb = reinterpret_cast<unsigned char*>(Hit + 2 * W2);         // [par][which][side][NVC]
+
+  const bool act = tid < 2 * nq;
+  const int side = act ? tid / nq : 0;
+  const int q = act ? tid - side * nq : 0;
+  const int ys = a.row0 + blockIdx.x * a.seg;
+  const int ye = min(ys + a.seg, a.row1);
+  const int pair = blockIdx.y;
+  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl;
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl;
+  const int xfirst0 = a.xo[0] - W2, xfirst1 = a.xo[1] - W2;
+  const int rb00 = a.rofs + clampi(xfirst0, -a.rofs, a.W - a.rofs - a.nd);
+  const int rb01 = a.rofs + clampi(xfirst1, -a.rofs, a.W - a.rofs - a.nd);
+  const int xfirst = side ? xfirst1 : xfirst0, rb0 = side ? rb01 : rb00;
+
+  // per virtual column: byte offset of this quad's window entry inside a staged piece
+  int off[NVC];
+#pragma unroll
+  for (int v = 0; v < NVC; v++) {
+    const int ov = a.rofs + clampi(xfirst + v, -a.rofs, a.W - a.rofs - a.nd) - rb0;   // 0 .. NVC-1
+    off[v] = ((ov & 3) * nsl + (ov >> 2) + q) * 8;
+  }
+  // vertical sums, packed 4 x u16 per virtual column, in ping-pong (mqsad may not overwrite a source): an entering
+  // row maps CA -> CB through the free accumulate, the leaving row maps CB -> CA with plain subtractions
+  uint2 CA[NVC];
+  u64 CB[NVC];
+#pragma unroll
+  for (int v = 0; v < NVC; v++) CA[v] = make_uint2(0u, 0u);
+  int Ct[2] = {0, 0};   // texture: this thread's entries e = tid, tid + T of the 2*NVC (side, virtual column) pairs
+
+  struct Staged { u64 r[RPT]; unsigned char l[2]; };
+  auto fetch = [&](int y) {
+    Staged g;
+    const uint8_t* lrow = pl + (size_t)y * a.pitch;
+    const uint8_t* rrow = pr + (size_t)y * a.pitch;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int e = tid + k * T;                      // entry index over both sides
+      u64 v = 0;
+      if (e < 2 * npiece) {
+        const int sd = e >= npiece, pp = e - sd * npiece;
+        __builtin_memcpy(&v, rrow + (sd ? rb01 : rb00) + pp, 8);
+      }
+      g.r[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int e = tid + k * T;
+      unsigned char lv = 0;
+      if (e < 2 * NVC) {
+        const int sd = e >= NVC, v = e - sd * NVC;
+        lv = lrow[a.lofs + clampi((sd ? xfirst1 : xfirst0) + v, -a.lofs, a.W - a.lofs - 1)];
+      }
+      g.l[k] = lv;
+    }
+    return g;
+  };
+  auto commit = [&](const Staged& g, int par, int which) {
+    u64* rb = Rb + (size_t)((par * 2 + which) * 2) * 4 * nsl;
+    unsigned char* lb = Lb + ((par * 2 + which) * 2) * NVC;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int e = tid + k * T;
+      if (e < 2 * npiece) {
+        const int sd = e >= npiece, pp = e - sd * npiece;
+        rb[sd * 4 * nsl + (pp & 3) * nsl + (pp >> 2)] = g.r[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int e = tid + k * T;
+      if (e < 2 * NVC) lb[e] = g.l[k];     // e = side*NVC + v
+    }
+  };
+  // mode 0: CB = CA + row (enter)   mode 1: CA = CB - row (leave)   mode 2: CA = CB + row (second of a prime pair)
+  auto accumulate = [&](int par, int which, const int mode) {
+    const unsigned char* rbb = reinterpret_cast<const unsigned char*>(Rb + (size_t)((par * 2 + which) * 2 + side) * 4 * nsl);
+    const unsigned char* lb = Lb + ((par * 2 + which) * 2 + side) * NVC;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < NVC; v++) {
+        const unsigned l = lb[v];
+        const u64 win = *reinterpret_cast<const u64*>(rbb + off[v]);
+        if (mode == 0) {
+          CB[v] = __builtin_amdgcn_mqsad_pk_u16_u8(win, l, __builtin_bit_cast(u64, CA[v]));
+        } else if (mode == 2) {
+          CA[v] = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, l, CB[v]));
+        } else {
+          const uint2 t = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, l, 0ull));
+          const uint2 cb = __builtin_bit_cast(uint2, CB[v]);
+          CA[v].x = cb.x - t.x;   // no u16 borrows: sums are exact
+          CA[v].y = cb.y - t.y;
+        }
+      }
+    }
+    const unsigned char* lall = Lb + ((par * 2 + which) * 2) * NVC;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int e = tid + k * T;
+      if (e < 2 * NVC) {
+        const int t = (int)lall[e] - a.capb;
+        const int at = t < 0 ? -t : t;
+        Ct[k] += mode == 1 ? -at : at;
+      }
+    }
+  };
+
+  // prime: rows ys-W2 .. ys+W2-1 (an even count) in CA -> CB -> CA pairs, fetching one row ahead
+  int par = 0;
+  Staged ge = fetch(ys - W2);
+  for (int yy = ys - W2; yy < ys + W2; yy += 2) {
+    commit(ge, par, 0);
+    Staged g1 = fetch(yy + 1);
+    __syncthreads();
+    accumulate(par, 0, 0);
+    par ^= 1;
+    commit(g1, par, 0);
+    ge = fetch(yy + 2);             // the last one fetched is row ys+W2: the first output row's entering row
+    __syncthreads();
+    accumulate(par, 0, 2);
+    par ^= 1;
+  }
+  if (tid < 2 * W2) Hit[tid] = 0;
+
+  Staged gl = fetch(ys - W2);       // leaving row of the first output row
+  for (int y = ys; y < ye; y++) {
+    commit(ge, par, 0);
+    commit(gl, par, 1);
+    __syncthreads();
+    if (y + 1 < ye) {               // next iteration's rows: entering y+1+W2, leaving y+1-W2
+      ge = fetch(y + 1 + W2);
+      gl = fetch(y + 1 - W2);
+    }
+    accumulate(par, 0, 0);          // CB = window rows y-W2 .. y+W2
+
+    // sliding sums over the virtual columns -> W2 outputs, 4 disparities each; publish sums and the local best key
+    u64 S[W2];
+    if (act) {
+      unsigned lo = 0, hi = 0;
+#pragma unroll
+      for (int v = 0; v < WSZ; v++) { lo += (unsigned)CB[v]; hi += (unsigned)(CB[v] >> 32); }
+#pragma unroll
+      for (int j = 0; j < W2; j++) {
+        S[j] = ((u64)hi << 32) | lo;
+        *reinterpret_cast<u64*>(Sb + ((size_t)(side * W2 + j) * a.nd + 4 * q)) = S[j];
+        const unsigned d0 = 4u * q;
+        const unsigned k0 = (lo << 16) | d0, k1 = (lo & 0xffff0000u) | (d0 + 1);
+        const unsigned k2 = (hi << 16) | (d0 + 2), k3 = (hi & 0xffff0000u) | (d0 + 3);
+        Kb[(side * W2 + j) * nq + q] = min(min(k0, k1), min(k2, k3));
+        if (j + 1 < W2) {
+          lo += (unsigned)CB[j + WSZ] - (unsigned)CB[j];
+          hi += (unsigned)(CB[j + WSZ] >> 32) - (unsigned)(CB[j] >> 32);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int e = tid + k * T;
+      if (e < 2 * NVC) Tc[e] = Ct[k];
+    }
+    __syncthreads();
+    if (tid < 2 * W2) {             // one lane per (side, output column): reduce the quads' local bests
+      const int sd = tid / W2, j = tid - sd * W2;
+      unsigned best = 0xffffffffu;
+      for (int qq = 0; qq < nq; qq++) best = min(best, Kb[(sd * W2 + j) * nq + qq]);
+      Best[tid] = best;
+      int ts = 0;
+      for (int v = 0; v < WSZ; v++) ts += Tc[sd * NVC + j + v];
+      Tsum[tid] = ts;
+    }
+    __syncthreads();
+    if (act && a.uniq > 0) {
+#pragma unroll
+      for (int j = 0; j < W2; j++) {
+        const unsigned best = Best[side * W2 + j];
+        const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
+        const int thresh = minsad + (minsad * a.uniq / 100);
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int d = 4 * q + i;
+          const int sv = (int)((S[j] >> (16 * i)) & 0xffffu);
+          hit |= (d < mind - 1 || d > mind + 1) && sv <= thresh;
+        }
+        if (hit) Hit[side * W2 + j] = 1;
+      }
+    }
+    accumulate(par, 1, 1);          // CA = CB - leaving row (independent of the WTA merge; overlaps its latency)
+    par ^= 1;
+    __syncthreads();
+    if (tid < 2 * W2) {
+      const int sd = tid / W2, j = tid - sd * W2;
+      const unsigned best = Best[tid];
+      const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
+      const bool ok = Tsum[tid] >= a.tex && Hit[tid] == 0;
+      Hit[tid] = 0;
+      int out = a.filtered;
+      const size_t o = (size_t)pair * a.W * a.H + (size_t)y * a.W + a.lofs + a.xo[sd] + j;
+      if (ok) {
+        const unsigned short* sb = Sb + (size_t)(sd * W2 + j) * a.nd;
+        const int p = mind + 1 < a.nd ? sb[mind + 1] : sb[a.nd - 2];
+        const int n = mind - 1 >= 0 ? sb[mind - 1] : sb[1];
+        const int ad = p > n ? p - n : n - p;
+        const int den = p + n - 2 * minsad + ad;
+        out = ((a.nd - mind - 1 + a.mindisp) * 256 + (den != 0 ? (p - n) * 256 / den : 0) + 15) >> 4;
+        if (a.cost) {
+          if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)minsad;
+          else static_cast<int32_t*>(a.cost)[o] = minsad;
+        }
+      }
+      a.disp[o] = (int16_t)out;
+    }
+    // the next iteration's first __syncthreads orders the reuse of Sb/Kb/Tc/Best/Tsum; Hit was reset by its reader
+  }
+}
+
 bool sad_border_supported(const Geom& g) { return sad_fast_supported(g); }
 
 hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
@@ -201,19 +444,41 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   const int rows = g.row1 - g.row0;
   // short segments: each row costs a latency-bound staging round trip, so favour many concurrent workgroups
   static const int seg_rows_env = [] { const char* e = getenv("SBM_BORDER_SEG"); return e ? atoi(e) : 0; }();
-  // The kernel runs on a side stream concurrently with the VALU-bound interior kernel, so what it costs is its
-  // instruction total (priming = w-1 extra rows per segment) -- as long as its critical path, (seg + w - 1) row steps
-  // of ~6 us each (two barriers per row), stays inside the interior kernel's duration. Estimate that duration from
-  // the interior kernel's measured rate (~3e12 pixel-disparities/s) and spend 60 % of it.
+  // The kernel runs on a side stream concurrently with the interior kernel. It is register-heavy (one of its
+  // wavefronts displaces two of the interior kernel's) and latency-bound (barriers + serial merge per row), so the
+  // best split is many short segments: measured flat optimum 12-24 rows on KITTI w15, 640x480 w21 and 1080p w21.
+  static const int version_env = [] { const char* e = getenv("SBM_BORDER_V"); return e ? atoi(e) : 0; }();
+  // quad-per-lane kernel up to 128 disparities (one wavefront per workgroup); beyond that its two-wavefront workgroups
+  // with 256 VGPRs become the tail of the step (measured at 1080p nd256: 3.75 vs 3.64 ms) -> per-disparity kernel
+  const int version = version_env ? version_env : (g.nd <= 128 ? 2 : 1);
   int seg_rows = seg_rows_env;
   if (seg_rows <= 0) {
-    const double t_interior_us = (double)g.n * g.W * (g.row1 - g.row0) * g.nd / 3.0e12 * 1e6;
-    seg_rows = (int)(0.6 * t_interior_us / 6.0) - (g.wsz - 1);
+    if (version != 1) {
+      seg_rows = 12;
+    } else {
+      const double t_interior_us = (double)g.n * g.W * (g.row1 - g.row0) * g.nd / 3.0e12 * 1e6;
+      seg_rows = (int)(0.6 * t_interior_us / 6.0) - (g.wsz - 1);
+    }
     seg_rows = std::max(12, std::min(seg_rows, rows));
   }
   int nseg = std::max(1, rows / seg_rows);
   a.seg = (rows + nseg - 1) / nseg;
   nseg = (rows + a.seg - 1) / a.seg;
+  if (version != 1) {
+    const int NVC = 3 * g.w2, nq = g.nd / 4, nsl = (NVC + g.nd) / 4 + 2;
+    const size_t lds = (size_t)2 * 2 * 2 * 4 * nsl * 8 + (size_t)2 * g.w2 * g.nd * 2 + (size_t)2 * g.w2 * nq * 4 +
+                       (size_t)2 * NVC * 4 + (size_t)3 * 2 * g.w2 * 4 + (size_t)2 * 2 * 2 * NVC + 16;
+    dim3 grid2(nseg, g.n);
+    dim3 block2(64 * ((2 * nq + 63) / 64));
+    switch (g.w2) {
+      case 4: hipLaunchKernelGGL(sad_border2_kernel<4>, grid2, block2, lds, s, a); break;
+      case 7: hipLaunchKernelGGL(sad_border2_kernel<7>, grid2, block2, lds, s, a); break;
+      case 10: hipLaunchKernelGGL(sad_border2_kernel<10>, grid2, block2, lds, s, a); break;
+      case 13: hipLaunchKernelGGL(sad_border2_kernel<13>, grid2, block2, lds, s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   dim3 grid(2 * nseg, g.n);
   dim3 block(64 * ((g.nd + 63) / 64));
   switch (g.w2) {
