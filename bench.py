@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--check", action="store_true", help="also verify pair 0 of rank 0 against the oracle")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: also gather every step's disparity maps on rank 0 (RCCL) inside the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,8 +126,15 @@ def main():
     bm.set_profiling(2)  # stage events recorded on the engine's stream, no host sync inside the timed region
     sync_all()
     t0 = time.perf_counter()
+    gathered = None
     for _ in range(args.steps):
         bm.launch_raw(B, pl, pr, W, H, pd)
+        if args.gather and dist is not None:
+            from u96_slam_amd import shard
+
+            bm.synchronize()
+            src = dD if backend == "nccl" else dD.cpu()
+            gathered = shard.gather_disparities(src, world * B, dst=0)
     bm.synchronize()
     torch.cuda.synchronize(dev)
     if dist is not None:
@@ -197,7 +206,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H} gray, ndisp={nd}, {wsz}x{wsz} SAD, "
                        + ("texture 10 / uniqueness 10 / disp12MaxDiff 1 / speckle 50,32" if post else "texture 10 / uniqueness 10, no LR/speckle"),
-                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, no data-path collective"},
+                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, " + ("disparity maps gathered on rank 0 each step" if (args.gather and world > 1) else "no data-path collective")},
             "ms_per_pair": round(elapsed / (B * args.steps) * 1e3, 5),
             "pairs_per_s": round(total_pairs / elapsed, 1),
             "roofline": roofline, "cpu_baseline": cpu,
