@@ -160,6 +160,7 @@ def main():
         algo_bytes = 4.0 * W * H * B  # read L+R (2 B/px) + write int16 disparity (2 B/px) per pair
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         traffic = None
+        pmc_extra = {}
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():
             try:
@@ -167,13 +168,15 @@ def main():
                 key = f"{args.workload}_w{wsz}_b{B}"
                 if key in tj:
                     traffic = tj[key]["bytes_per_launch"]
+                    # what actually bounds the kernel: VALU issue, from the same committed PMC run
+                    pmc_extra = {k: tj[key][k] for k in ("valu_busy_frac", "lds_busy_frac") if k in tj[key]}
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "sad_fast_kernel" if stage == "sad" else "sad_generic_kernel",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                    "stage_ms": {k: round(v, 4) for k, v in prof.items()}}
+                    "stage_ms": {k: round(v, 4) for k, v in prof.items()}, **pmc_extra}
 
         # ---- CPU baseline (reported only) --------------------------------------------------------------------------
         cpu = None

@@ -5,21 +5,23 @@
 // src/slam/src/core/main.cpp:215.  In-tree hardware twins: src/dvp/rtl/bm_calc_sad.v:391-605 (34-lane abs-diff,
 // vertical running sums, horizontal running SAD), bm_calc_det.v:124-426 (WTA tree), bm_calc_frac.v (sub-pixel).
 //
-// Mapping (one 64-lane wavefront = one workgroup; no barriers):
-//   lane      = one image column c (64 consecutive columns per wavefront), marching down a row segment
+// Mapping (a workgroup = NWAVES cooperating wavefronts over the SAME 64 columns; wavefront k owns disparities
+// [NDW*k, NDW*k+NDW); two barriers per row where NWAVES > 1, none otherwise):
+//   lane      = one image column c (64 consecutive columns per workgroup), marching down a row segment
 //   registers = V[d]: for every disparity the sum over the w window rows of the 3-column SAD
 //               H3(c,y,d) = sum_{i<3} |Lp[y][c+i] - Rp[y][c+i-D]|, packed 4 x u16 per VGPR pair.
 //               One v_mqsad_pk_u16_u8 produces H3 for 4 consecutive disparities AND accumulates (pattern = 3 left
 //               bytes + a zero byte, which the instruction masks; sliding 8-byte window = right bytes).
-//               Entering row: V = mqsad(R, L, V).  Leaving row: V -= mqsad(R, L, 0).
+//               Entering row: VB = mqsad(R, L, VA).  Leaving row: VA = VB - mqsad(R, L, 0)  (dst may not alias a source).
 //   LDS       = the right row piece of the wavefront, expanded 16x (slot p holds bytes p..p+15) so that every lane's
 //               16-byte-aligned ds_read_b128 stream starts at its own byte offset; conflict-free (lane stride 16 B).
-//   exchange  = horizontal window: S(c + w/2) = sum_k V(c + 3k), k < w/3: lanes publish V to LDS ([quad][lane], 8 B
-//               entries) and read the shifted copies back (conflict-free b64 traffic); lanes whose partners fall
+//   exchange  = horizontal window: S(c + w/2) = sum_k V(c + 3k), k < w/3: lanes publish V to LDS ([quad pair][lane],
+//               16 B entries) and read the shifted copies back (conflict-free b128 traffic); lanes whose partners fall
 //               outside the wavefront (the last w-3) produce nothing and are recomputed by the next strip.
 //   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan),
-//               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree.
-// Envelope (checked on the host, everything else takes the generic kernel): w in {9,15,21,27}, nd <= 128,
+//               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree; per-wavefront
+//               results merged through LDS, one wavefront (alternating per row) finishes and stores.
+// Envelope (checked on the host, everything else takes the generic kernel): w in {9,15,21,27}, nd <= 256,
 // w*w*2*cap <= 65534 (16-bit sums), 2*(maxS*uniq/100+1) < 65535, valid-ROI rows inside [w/2, H-w/2).
 #include <stdlib.h>
 
