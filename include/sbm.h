@@ -159,6 +159,41 @@ int sbm_reproject_device(sbm_handle* h, int n, const void* d_disp, int width, in
 int sbm_keypoints3d_device(sbm_handle* h, const void* d_disp, int width, int height, const void* d_kpts, int nk,
                            const sbm_stereo_model* model, float min_depth, float max_depth, void* d_xyz, int sync);
 
+/* ---- producers in front of the path (SURVEY.md 8f rank 2 and the prefilter half of rank 3) -------------------------
+ * Device-resident versions of the two stages the reference's FPGA flavour runs before block matching, so raw camera
+ * frames can enter the engine without a host round trip:
+ *   rectification   inverse map: rect_remap(), src/StereoBM/src/fpga.c:303-366 (s1.24 fixed point; the RTL twin is
+ *                   src/dvp/rtl/rect_rmp.v:339-572); bilinear resampling with 5-bit fractions:
+ *                   src/dvp/rtl/rect_intp.v:285-404
+ *   x-Sobel         stand-alone prefilter of dense images, either flavour: cv prefilterXSobel (what sbm_compute runs
+ *                   internally) or the RTL's src/dvp/rtl/xsbl2.v:185-198,661-874 (clip to [-32,31], +32; rows 0 and
+ *                   H-1 unwritten = 0) -- the flavour data/ref_xsbl_{l,r} was produced with.
+ * Integer arithmetic throughout; results are bit-identical to the reference's C / RTL expressions. */
+typedef struct sbm_rect_cam {   /* struct RECT_PARAM_CH, src/StereoBM/src/fpga.h:250-256 (one camera)                  */
+  int32_t f[2];                 /* focal length x, y of the source camera, u10.16                                      */
+  int32_t c[2];                 /* principal point x, y of the source camera, integer pixels                           */
+  int32_t f2inv[2];             /* 1 / f2 of the rectified camera, u-8.32                                              */
+  int32_t c2_f2[2];             /* c2 / f2 of the rectified camera, u0.24                                              */
+  int32_t rot[3][3];            /* inverted rotation, s0.24, indexed as the firmware does (rot[row][col])              */
+} sbm_rect_cam;
+
+/* d_map: height*width*2 int16, (x, y) interleaved, source coordinates in 1/32 px (what rect_remap() stores in
+ * MAT2S.data[0] / data[1]). Depends on the camera only: build once, reuse for every frame. */
+int sbm_rect_map_device(sbm_handle* h, const sbm_rect_cam* cam, int width, int height, void* d_map, int sync);
+
+/* dst[i] = bilinear(src[i], map) for n dense u8 images sharing one map:
+ *   ((UL*(32-xf)*(32-yf) + UR*xf*(32-yf) + DL*(32-xf)*yf + DR*xf*yf) >> 9) + 1) >> 1, taps at (x>>5, y>>5) and +1.
+ * Taps outside the source image read as 0 (the RTL reads stale line-buffer contents there; calibrated rigs keep the
+ * valid region inside). */
+int sbm_rect_remap_device(sbm_handle* h, int n, const void* d_src, const void* d_map, int width, int height, void* d_dst,
+                          int sync);
+
+#define SBM_PREFILTER_FLAVOUR_CV 0  /* clip(s,-cap,cap)+cap, reflect-101 rows, odd H: last row = cap */
+#define SBM_PREFILTER_FLAVOUR_RTL 1 /* clip(s,-32,31)+32, rows 0 and H-1 = 0 (cap ignored)           */
+/* n dense u8 images -> n dense u8 planes. */
+int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int height, int flavour, int cap,
+                         void* d_dst, int sync);
+
 /* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours. */
 void* sbm_stream(sbm_handle* h);
 

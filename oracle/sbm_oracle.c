@@ -533,6 +533,60 @@ int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const
   return SBM_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Rectification, FPGA flavour (the only flavour of the reference that rectifies).
+ *
+ * sbmo_rect_map follows rect_remap() of src/StereoBM/src/fpga.c:303-366: destination pixel -> normalised
+ * rectified ray -> rotate back -> perspective divide -> source pixel, all in s1.24 fixed point with the
+ * firmware's shifts and its UNSIGNED 2^48 / lw division; the stored coordinate is s10.5 (1/32 px), rounded
+ * from s10.6 by (v + 1) >> 1, truncated to 16 bits.
+ * ------------------------------------------------------------------------------------------------ */
+static inline int64_t rect_coord(int64_t num, int64_t lw_inv, int32_t f, int32_t c) {
+  const int64_t n2 = (num * lw_inv) >> 24;       /* s1.24 * s1.24 -> s1.24 */
+  const int64_t nf = (n2 * (int64_t)f) >> 34;    /* s1.24 * u10.16 -> s10.6 */
+  const int64_t v = nf + ((int64_t)c << 6);      /* + principal point */
+  return (v + 1) >> 1;                           /* s10.5 */
+}
+
+void sbmo_rect_map(const sbm_rect_cam* cam, int width, int height, int16_t* map) {
+  for (int yd = 0; yd < height; yd++) {
+    for (int xd = 0; xd < width; xd++) {
+      /* normalised coordinates in the rectified camera: dst / f2 - c2 / f2 */
+      const int64_t xn = (((int64_t)xd * (int64_t)cam->f2inv[0]) >> 8) - (int64_t)cam->c2_f2[0];
+      const int64_t yn = (((int64_t)yd * (int64_t)cam->f2inv[1]) >> 8) - (int64_t)cam->c2_f2[1];
+      /* [lx ly lw] = [xn yn 1] * rot  (rot[2][*] enters unscaled: the homogeneous 1) */
+      int64_t l[3];
+      for (int k = 0; k < 3; k++)
+        l[k] = (((int64_t)cam->rot[0][k] * xn) >> 24) + (((int64_t)cam->rot[1][k] * yn) >> 24) + (int64_t)cam->rot[2][k];
+      /* the firmware divides (1ull << 48) by lw converted to unsigned */
+      const uint64_t den = (uint64_t)l[2];
+      const int64_t lw_inv = den ? (int64_t)(((uint64_t)1 << 48) / den) : 0;
+      int16_t* m = map + ((size_t)yd * width + xd) * 2;
+      m[0] = (int16_t)rect_coord(l[0], lw_inv, cam->f[0], cam->c[0]);
+      m[1] = (int16_t)rect_coord(l[1], lw_inv, cam->f[1], cam->c[1]);
+    }
+  }
+}
+
+/* rect_intp.v:285-404: u0.5 fractions, u1.10 weight products, u8.10 sum, >> 9, + 1, >> 1. */
+void sbmo_rect_remap(const uint8_t* src, const int16_t* map, int width, int height, uint8_t* dst) {
+  for (int y = 0; y < height; y++) {
+    for (int x = 0; x < width; x++) {
+      const int mx = map[((size_t)y * width + x) * 2], my = map[((size_t)y * width + x) * 2 + 1];
+      const int xi = mx >> 5, yi = my >> 5, xf = mx & 31, yf = my & 31;
+      int tap[2][2];
+      for (int dy = 0; dy < 2; dy++)
+        for (int dx = 0; dx < 2; dx++) {
+          const int sx = xi + dx, sy = yi + dy;
+          tap[dy][dx] = (sx >= 0 && sx < width && sy >= 0 && sy < height) ? src[(size_t)sy * width + sx] : 0;
+        }
+      const int acc = tap[0][0] * ((32 - xf) * (32 - yf)) + tap[0][1] * (xf * (32 - yf)) + tap[1][0] * ((32 - xf) * yf) +
+                      tap[1][1] * (xf * yf);
+      dst[(size_t)y * width + x] = (uint8_t)(((acc >> 9) + 1) >> 1);
+    }
+  }
+}
+
 int sbmo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

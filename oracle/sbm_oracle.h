@@ -88,6 +88,14 @@ void sbmo_reproject(const int16_t* disp, int width, int height, int scale, const
 void sbmo_keypoints3d(const int16_t* disp, int width, int height, const float* kpts, int nk, const sbm_stereo_model* m,
                       float min_depth, float max_depth, float* xyz);
 
+/* Producers in front of the path, restated from the reference's firmware C and RTL:
+ * inverse rectification map = rect_remap(), src/StereoBM/src/fpga.c:303-366; bilinear resampling with 5-bit
+ * fractions = src/dvp/rtl/rect_intp.v:285-404. PARITY UNPINNED for the resampled image: the reference ships no raw
+ * camera frame (data/ref_rect_* are already rectified), so there is no golden vector for this stage; the map function
+ * is integer C in the reference and is restated expression by expression. Taps outside the source image read as 0. */
+void sbmo_rect_map(const sbm_rect_cam* cam, int width, int height, int16_t* map);
+void sbmo_rect_remap(const uint8_t* src, const int16_t* map, int width, int height, uint8_t* dst);
+
 int sbmo_max_threads(void);
 
 #ifdef __cplusplus

@@ -42,6 +42,25 @@ class StereoModel(ctypes.Structure):
         ("local", ctypes.c_float * 12), ("has_local", ctypes.c_int32)]
 
 
+class RectCam(ctypes.Structure):
+    """Mirror of `sbm_rect_cam` (include/sbm.h)."""
+
+    _fields_ = [("f", ctypes.c_int32 * 2), ("c", ctypes.c_int32 * 2), ("f2inv", ctypes.c_int32 * 2),
+                ("c2_f2", ctypes.c_int32 * 2), ("rot", (ctypes.c_int32 * 3) * 3)]
+
+
+def make_rect_cam(f, c, f2inv, c2_f2, rot):
+    cam = RectCam()
+    cam.f[:] = [int(v) for v in f]
+    cam.c[:] = [int(v) for v in c]
+    cam.f2inv[:] = [int(v) for v in f2inv]
+    cam.c2_f2[:] = [int(v) for v in c2_f2]
+    for r in range(3):
+        for k in range(3):
+            cam.rot[r][k] = int(rot[r][k])
+    return cam
+
+
 def make_model(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, baseline=0.537, cx_r=None, local=None):
     """KITTI-like rectified pair: P0 = [f 0 cx 0; ...], P1 = [f 0 cx -f*b; ...]."""
     m = StereoModel()
@@ -113,6 +132,10 @@ def lib():
         L.sbmo_reproject.restype = None
         L.sbmo_keypoints3d.argtypes = [i16p, ci, ci, f32p, ci, mp, ctypes.c_float, ctypes.c_float, f32p]
         L.sbmo_keypoints3d.restype = None
+        L.sbmo_rect_map.argtypes = [ctypes.POINTER(RectCam), ci, ci, i16p]
+        L.sbmo_rect_map.restype = None
+        L.sbmo_rect_remap.argtypes = [u8p, i16p, ci, ci, u8p]
+        L.sbmo_rect_remap.restype = None
         _LIB = L
     return _LIB
 
@@ -251,3 +274,19 @@ def keypoints3d(disp, kpts, model, min_depth=0.0, max_depth=0.0):
     lib().sbmo_keypoints3d(_p(disp, ctypes.c_int16), w, h, _p(kpts, ctypes.c_float), len(kpts), ctypes.byref(model),
                            min_depth, max_depth, _p(xyz, ctypes.c_float))
     return xyz
+
+
+def rect_map(cam, width, height):
+    """rect_remap() of the reference firmware restated: int16 (H, W, 2), (x, y) in 1/32 source pixels."""
+    m = np.empty((height, width, 2), np.int16)
+    lib().sbmo_rect_map(ctypes.byref(cam), width, height, _p(m, ctypes.c_int16))
+    return m
+
+
+def rect_remap(src, rmap):
+    src = _u8(src)
+    rmap = np.ascontiguousarray(rmap, dtype=np.int16)
+    h, w = src.shape
+    out = np.empty((h, w), np.uint8)
+    lib().sbmo_rect_remap(_p(src, ctypes.c_uint8), _p(rmap, ctypes.c_int16), w, h, _p(out, ctypes.c_uint8))
+    return out

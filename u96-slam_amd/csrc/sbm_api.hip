@@ -359,6 +359,42 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   return SBM_OK;
 }
 
+int sbm_rect_map_device(sbm_handle* h, const sbm_rect_cam* cam, int width, int height, void* d_map, int sync) {
+  if (!h || !cam || !d_map) return SBM_ERR_NULL;
+  if (width <= 0 || height <= 0 || width > 32767 || height > 32767) return SBM_ERR_SIZE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_rect_map(*cam, width, height, (int16_t*)d_map, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_rect_remap_device(sbm_handle* h, int n, const void* d_src, const void* d_map, int width, int height, void* d_dst,
+                          int sync) {
+  if (!h || !d_src || !d_map || !d_dst) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  if (width <= 0 || height <= 0 || width > 32767 || height > 32767) return SBM_ERR_SIZE;
+  if (((size_t)width * height + 1023) / 1024 > 65535) return SBM_ERR_UNSUPPORTED;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_rect_remap((const uint8_t*)d_src, (const int16_t*)d_map, (uint8_t*)d_dst, n, width, height, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int height, int flavour, int cap,
+                         void* d_dst, int sync) {
+  if (!h || !d_src || !d_dst) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  if (width <= 0 || height <= 0) return SBM_ERR_SIZE;
+  if (flavour != SBM_PREFILTER_FLAVOUR_CV && flavour != SBM_PREFILTER_FLAVOUR_RTL) return SBM_ERR_PREFILTER_TYPE;
+  if (flavour == SBM_PREFILTER_FLAVOUR_CV && (cap < 1 || cap > 63)) return SBM_ERR_PREFILTER_CAP;
+  if (n > 65534 || height > 65535 * 4) return SBM_ERR_UNSUPPORTED;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_src, (uint8_t*)d_dst, n, width, height,
+                                   flavour == SBM_PREFILTER_FLAVOUR_RTL, cap, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
 int sbm_decimate_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale, void* d_out, int sync) {
   if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;

@@ -56,6 +56,13 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
                           hipStream_t s);
 
+// Stand-alone prefilter of dense images (either flavour) and the rectifier in front of it (sbm_rectify.hip).
+hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, int W, int H, int rtl, int cap,
+                                  hipStream_t s);
+hipError_t launch_rect_map(const sbm_rect_cam& cam, int W, int H, int16_t* d_map, hipStream_t s);
+hipError_t launch_rect_remap(const uint8_t* d_src, const int16_t* d_map, uint8_t* d_dst, int n, int W, int H,
+                             hipStream_t s);
+
 // Consumers of the map (sbm_consume.hip): decimation, reprojection, keypoint depth.
 hipError_t launch_decimate(const int16_t* disp, int16_t* out, int n, int W, int H, int scale, hipStream_t s);
 hipError_t launch_reproject(const int16_t* disp, float* xyz, int n, int W, int H, int scale, const sbm_stereo_model& m,

@@ -19,7 +19,13 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   return v;
 }
 
-__device__ __forceinline__ int clipcap(int v, int cap) { return (v < -cap ? -cap : (v > cap ? cap : v)) + cap; }
+// value mapping of one flavour: out = clip(s, lo, hi) + off (+ bias of the destination plane)
+//   cv  (prefilterXSobel):  lo = -cap, hi = cap, off = cap; reflect-101 rows; odd H: last row = cap
+//   rtl (xsbl2.v:185-198):  lo = -32,  hi = 31,  off = 32;  rows 0 and H-1 are never written by the RTL (= 0)
+struct PfMap {
+  int lo, hi, off, bias, rtl;
+};
+__device__ __forceinline__ int clipmap(int v, const PfMap& m) { return (v < m.lo ? m.lo : (v > m.hi ? m.hi : v)) + m.off; }
 
 __device__ __forceinline__ uint4 load_u128_ua(const uint8_t* p) {
   uint4 v;
@@ -41,7 +47,7 @@ constexpr int PF_ROWS = 4;
 // grid: x = ceil(ceil(H/PF_ROWS)*ceil(W/16)/256), y = 2*n (image index: even = left, odd = right)
 __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                         uint8_t* __restrict__ pf_l, uint8_t* __restrict__ pf_r, int W, int H,
-                                                        int pitch, int padl, int plane, int cap) {
+                                                        int pitch, int padl, size_t sstride, size_t plane, PfMap m) {
   // threads are flattened over (row group, 16-pixel piece) of one image so that every lane has work whatever the width
   const int npiece = (W + 15) / 16;
   const int ngroup = (H + PF_ROWS - 1) / PF_ROWS;
@@ -51,8 +57,8 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
   const int y0 = yg * PF_ROWS;
   const int x0 = (t - yg * npiece) * 16;
   const int img = blockIdx.y >> 1;
-  const uint8_t* src = ((blockIdx.y & 1) ? right : left) + (size_t)img * W * H;
-  uint8_t* dst0 = ((blockIdx.y & 1) ? pf_r : pf_l) + (size_t)img * plane + padl + x0;
+  const uint8_t* src = ((blockIdx.y & 1) ? right : left) + (size_t)img * sstride;
+  uint8_t* dst0 = ((blockIdx.y & 1) ? pf_r : pf_l) + img * plane + padl + x0;
   const bool interior = x0 >= 16 && x0 + 32 <= W;
 
   // packed pieces of source rows y0-1 .. y0+PF_ROWS (reflect-101 at the image border): bytes x0-1 .. x0+18
@@ -86,8 +92,8 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
     const int y = y0 + j;
     if (y >= H) break;
     uint32_t out[4];
-    if ((H & 1) && y == H - 1) {
-      out[0] = out[1] = out[2] = out[3] = (uint32_t)(cap + kPfBias) * 0x01010101u;
+    if (m.rtl ? (y == 0 || y == H - 1) : ((H & 1) && y == H - 1)) {
+      out[0] = out[1] = out[2] = out[3] = (uint32_t)((m.rtl ? 0 : m.off) + m.bias) * 0x01010101u;
     } else {
       int s[18];  // vertical 1-2-1 sums of columns x0-1 .. x0+16
 #pragma unroll
@@ -105,15 +111,20 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int x = x0 + 4 * k + i;
-          const int v = (x == 0 || x >= W - 1) ? cap : clipcap(s[4 * k + i + 2] - s[4 * k + i], cap);
-          o |= (uint32_t)(v + kPfBias) << (8 * i);
+          const int v = (x == 0 || x >= W - 1) ? m.off : clipmap(s[4 * k + i + 2] - s[4 * k + i], m);
+          o |= (uint32_t)(v + m.bias) << (8 * i);
         }
         out[k] = o;
       }
     }
     uint8_t* dst = dst0 + (size_t)y * pitch;
     if (x0 + 16 <= W) {
-      *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);  // pitch, padl multiples of 16
+      if (((pitch | padl) & 15) == 0) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);  // engine planes: 16-byte aligned
+      } else {
+        const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
+        __builtin_memcpy(dst, &o4, 16);                                                // dense caller-owned plane
+      }
     } else {
       for (int i = 0; x0 + i < W; i++) dst[i] = (uint8_t)(out[i >> 2] >> (8 * (i & 3)));
     }
@@ -125,8 +136,30 @@ hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8
   const int npiece = (g.W + 15) / 16;
   const int ngroup = (g.H + PF_ROWS - 1) / PF_ROWS;
   dim3 grid((npiece * ngroup + 255) / 256, 2 * g.n);
+  const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0};
   hipLaunchKernelGGL(prefilter_kernel, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl,
-                     g.plane, g.cap);
+                     (size_t)g.W * g.H, (size_t)g.plane, m);
+  return hipGetLastError();
+}
+
+// Stand-alone prefilter of n dense images into n dense planes (no padding, no bias), either flavour.
+hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, int W, int H, int rtl, int cap,
+                                  hipStream_t s) {
+  const int npiece = (W + 15) / 16;
+  const int ngroup = (H + PF_ROWS - 1) / PF_ROWS;
+  // the kernel addresses images as (pair, side): image j = pair j/2, side j&1, so a dense array of images is a
+  // sequence of pairs with a stride of two images; an odd last image goes in a second launch of one side
+  const PfMap m = rtl ? PfMap{-32, 31, 32, 0, 1} : PfMap{-cap, cap, cap, 0, 0};
+  const size_t img = (size_t)W * H;
+  const unsigned gx = (unsigned)((npiece * ngroup + 255) / 256);
+  if (n >= 2)
+    hipLaunchKernelGGL(prefilter_kernel, dim3(gx, 2 * (n / 2)), dim3(256), 0, s, d_src, d_src + img, d_dst, d_dst + img,
+                       W, H, W, 0, 2 * img, 2 * img, m);
+  if (n & 1) {
+    const size_t o = (size_t)(n - 1) * img;
+    hipLaunchKernelGGL(prefilter_kernel, dim3(gx, 1), dim3(256), 0, s, d_src + o, d_src + o, d_dst + o, d_dst + o, W, H, W,
+                       0, img, img, m);
+  }
   return hipGetLastError();
 }
 

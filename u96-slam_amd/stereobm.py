@@ -41,6 +41,29 @@ class StereoModel(ctypes.Structure):
         ("local", ctypes.c_float * 12), ("has_local", ctypes.c_int32)]
 
 
+class RectCam(ctypes.Structure):
+    """`sbm_rect_cam` of include/sbm.h = struct RECT_PARAM_CH (src/StereoBM/src/fpga.h:250-256), one camera."""
+
+    _fields_ = [("f", ctypes.c_int32 * 2), ("c", ctypes.c_int32 * 2), ("f2inv", ctypes.c_int32 * 2),
+                ("c2_f2", ctypes.c_int32 * 2), ("rot", (ctypes.c_int32 * 3) * 3)]
+
+
+def make_rect_cam(f, c, f2inv, c2_f2, rot):
+    cam = RectCam()
+    cam.f[:] = [int(v) for v in f]
+    cam.c[:] = [int(v) for v in c]
+    cam.f2inv[:] = [int(v) for v in f2inv]
+    cam.c2_f2[:] = [int(v) for v in c2_f2]
+    for r in range(3):
+        for k in range(3):
+            cam.rot[r][k] = int(rot[r][k])
+    return cam
+
+
+PREFILTER_FLAVOUR_CV = 0
+PREFILTER_FLAVOUR_RTL = 1
+
+
 class StereoBMError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"sbm status {code}: {message}")
@@ -88,6 +111,9 @@ def load_library():
     L.sbm_decimate_device.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci]
     L.sbm_reproject_device.argtypes = [vp, ci, vp, ci, ci, ci, mp, ci, vp, ci]
     L.sbm_keypoints3d_device.argtypes = [vp, vp, ci, ci, vp, ci, mp, ctypes.c_float, ctypes.c_float, vp, ci]
+    L.sbm_rect_map_device.argtypes = [vp, ctypes.POINTER(RectCam), ci, ci, vp, ci]
+    L.sbm_rect_remap_device.argtypes = [vp, ci, vp, vp, ci, ci, vp, ci]
+    L.sbm_prefilter_device.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci]
     L.sbm_stream.argtypes = [vp]
     L.sbm_stream.restype = vp
     L.sbm_strerror.argtypes = [ci]
@@ -273,6 +299,44 @@ class StereoBM:
                                               ctypes.byref(model), min_depth, max_depth, xyz.data_ptr(), 1), self._h)
         return xyz
 
+    # ---- producers in front of the path (fpga.c:303-366, rect_intp.v:285-404, xsbl2.v:661-874) --------------------
+    def rect_map(self, cam, width, height):
+        """Inverse rectification map of one camera: torch CUDA int16 (H, W, 2), (x, y) in 1/32 source pixels."""
+        import torch
+
+        m = torch.empty((height, width, 2), dtype=torch.int16, device=f"cuda:{self._device}")
+        _check(self._L.sbm_rect_map_device(self._h, ctypes.byref(cam), width, height, m.data_ptr(), 1), self._h)
+        return m
+
+    def rect_remap(self, src, rmap):
+        """torch CUDA uint8 (n,H,W) or (H,W) raw frames + a map from rect_map -> rectified frames, on the device."""
+        import torch
+
+        src, rmap = src.contiguous(), rmap.contiguous()
+        h, w = src.shape[-2], src.shape[-1]
+        if tuple(rmap.shape) != (h, w, 2) or rmap.dtype != torch.int16 or src.dtype != torch.uint8:
+            raise StereoBMError(-2, "map must be int16 (H,W,2) and frames uint8 (..,H,W)")
+        n = 1 if src.dim() == 2 else src.shape[0]
+        out = torch.empty_like(src)
+        torch.cuda.current_stream(src.device).synchronize()
+        _check(self._L.sbm_rect_remap_device(self._h, n, src.data_ptr(), rmap.data_ptr(), w, h, out.data_ptr(), 1), self._h)
+        return out
+
+    def prefilter(self, src, flavour=PREFILTER_FLAVOUR_CV, cap=None):
+        """Stand-alone x-Sobel prefilter of torch CUDA uint8 (n,H,W) or (H,W) frames, cv or RTL flavour."""
+        import torch
+
+        src = src.contiguous()
+        if src.dtype != torch.uint8 or not src.is_cuda:
+            raise StereoBMError(-2, "frames must be CUDA uint8 tensors")
+        h, w = src.shape[-2], src.shape[-1]
+        n = 1 if src.dim() == 2 else src.shape[0]
+        out = torch.empty_like(src)
+        torch.cuda.current_stream(src.device).synchronize()
+        _check(self._L.sbm_prefilter_device(self._h, n, src.data_ptr(), w, h, flavour,
+                                            self._p.prefilter_cap if cap is None else cap, out.data_ptr(), 1), self._h)
+        return out
+
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
 
@@ -280,7 +344,8 @@ class StereoBM:
         return self._L.sbm_stream(self._h)
 
     def set_profiling(self, on):
-        _check(self._L.sbm_set_profiling(self._h, 1 if on else 0), self._h)
+        # 0 = off, 1 = sync after every call, 2 = stage events only (no host sync; up to 64 calls per profile() read)
+        _check(self._L.sbm_set_profiling(self._h, int(on)), self._h)
 
     def profile(self):
         out = {}
