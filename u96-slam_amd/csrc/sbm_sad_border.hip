@@ -44,6 +44,8 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 
 template <int W2>
 __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
+  // these wavefronts are latency-bound and share their SIMDs with the VALU-bound interior kernel: let them issue first
+  __builtin_amdgcn_s_setprio(3);
   constexpr int NVC = 3 * W2, WSZ = 2 * W2 + 1;
   constexpr int RSPAN = NVC + 256;          // right bytes staged per row: rb(0) .. rb(0)+NVC+nd
   __shared__ uint8_t Lbuf[2][2][NVC + 1];   // [parity][enter/leave][virtual column] (clamp already applied)
@@ -197,6 +199,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char border_lds[];
 
 template <int W2>
 __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
+  // these wavefronts are latency-bound and share their SIMDs with the VALU-bound interior kernel: let them issue first
+  __builtin_amdgcn_s_setprio(3);
   constexpr int NVC = 3 * W2, WSZ = 2 * W2 + 1;
   constexpr int RPT = 6;                    // staged 8-byte entries per thread per row: 2*(NVC+nd) <= 6*T (host-checked)
   typedef unsigned long long u64;

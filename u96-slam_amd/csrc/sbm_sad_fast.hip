@@ -42,7 +42,8 @@ struct FastArgs {
   uint16_t* cost;            // 16-bit cost plane (sums fit by the envelope)
   int W, H, pitch, padl, plane;
   int nd, mindisp, lofs, rofs, tex, uniq, filtered, capb;
-  int row0, row1, seg;       // rows [row0,row1) in segments of `seg`
+  int row0, row1;            // rows [row0,row1)
+  int segrow[34];            // row segment k = rows [segrow[k], segrow[k+1]); long segments first, short ones last
   int strips, nseg, npairs;  // grid decomposition (1-D grid of strips*nseg*npairs workgroups)
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
 };
@@ -93,10 +94,15 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   // XCD-aware decode of the 1-D workgroup id: consecutive ids go round-robin over the 8 XCDs (each with its own
   // 4 MiB L2), so give XCD k the pairs k, k+8, ...: all strips and row segments of a pair then share one L2.
   // (Placement only affects speed; any mapping is correct.)
-  const int bpp = a.strips * a.nseg;                    // workgroups per pair
+  // Row segments are the slowest-varying index and get shorter towards the end of the grid: every segment pays w-1
+  // priming rows, so few long segments keep that overhead low while the short last ones keep the tail of the launch
+  // (CUs idling while the last workgroups finish) short.
+  const int bpp = a.strips;                             // workgroups per pair and segment
   int strip, segi, pair;
   {
-    const int b = blockIdx.x;
+    const int per_seg = a.strips * a.npairs;
+    segi = blockIdx.x / per_seg;
+    const int b = blockIdx.x - segi * per_seg;
     const int full = (a.npairs / 8) * 8 * bpp;          // ids covered by complete groups of 8 pairs
     int p, inner;
     if (b < full) {
@@ -109,14 +115,13 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
       inner = r % bpp;
     }
     pair = p;
-    strip = inner % a.strips;
-    segi = inner / a.strips;
+    strip = inner;
   }
   const int c = strip * NV + lane;                      // this lane's column (relative to lofs): V covers c..c+2
   const int xc = c + W2;                                // centre column this lane produces
   const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
-  const int ys = a.row0 + segi * a.seg;
-  const int ye = min(ys + a.seg, a.row1);
+  const int ys = a.segrow[segi];
+  const int ye = a.segrow[segi + 1];
   const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;  // left bytes of this lane
   // right piece of the wavefront: window of buffer index d starts at rofs + c + d
   const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + strip * NV + d0;
@@ -441,12 +446,30 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
   // segment at ~1/3 of a full row's cost) below ~10 %
   int nseg = 1;
-  const long target = 12000;  // measured on KITTI b64: 8-10 segments (11-14k workgroups) is the flat optimum
+  static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 9000L; }();
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
   static const int nseg_env = [] { const char* e = getenv("SBM_FAST_NSEG"); return e ? atoi(e) : 0; }();
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
-  a.seg = (rows + nseg - 1) / nseg;
-  nseg = (rows + a.seg - 1) / a.seg;
+  // taper: the last third of the rows is cut into segments of 2/3, 1/2, 1/3 ... of the regular length
+  static const int taper = [] { const char* e = getenv("SBM_FAST_TAPER"); return e ? atoi(e) : 1; }();
+  nseg = std::min(nseg, 32);
+  int ns = 0;
+  a.segrow[0] = g.row0;
+  if (!taper || nseg < 3) {
+    const int seg = (rows + nseg - 1) / nseg;
+    for (int y = g.row0; y < g.row1; y += seg) a.segrow[++ns] = std::min(y + seg, g.row1);
+  } else {
+    // nseg segments with weights 1,...,1, 3/4, 1/2, 1/4 (sum nseg - 1.5): fewer rows to prime than nseg equal ones
+    const double unit = rows / (nseg - 1.5);
+    double acc = 0;
+    for (int k = 0; k < nseg; k++) {
+      const double wgt = k < nseg - 3 ? 1.0 : (k == nseg - 3 ? 0.75 : (k == nseg - 2 ? 0.5 : 0.25));
+      acc += wgt * unit;
+      const int y = k == nseg - 1 ? g.row1 : std::min(g.row1, g.row0 + (int)(acc + 0.5));
+      if (y > a.segrow[ns]) a.segrow[++ns] = y;
+    }
+  }
+  nseg = ns;
   a.strips = strips; a.nseg = nseg; a.npairs = g.n;
   dim3 grid((unsigned)strips * nseg * g.n);
   hipError_t e;
