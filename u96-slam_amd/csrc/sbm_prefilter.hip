@@ -33,11 +33,17 @@ __device__ __forceinline__ uint4 load_u128_ua(const uint8_t* p) {
   return v;
 }
 
-// vertical 1-2-1 sums of 4 packed bytes, as two registers of 2 x u16 (even bytes / odd bytes): max 4*255 fits u16
-__device__ __forceinline__ void vsum4(uint32_t a, uint32_t b, uint32_t c, uint32_t& even, uint32_t& odd) {
-  const uint32_t m = 0x00ff00ffu;
-  even = (a & m) + 2u * (b & m) + (c & m);
-  odd = ((a >> 8) & m) + 2u * ((b >> 8) & m) + ((c >> 8) & m);
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// bytes (b0,b1,b2,b3) of a word -> packed u16 pairs: even = (b0, b2), odd = (b1, b3)
+__device__ __forceinline__ uint32_t even_bytes(uint32_t w) { return w & 0x00ff00ffu; }
+__device__ __forceinline__ uint32_t odd_bytes(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c01u); }
+
+// packed (2 x i16): clip(a - b, lo, hi) + off
+__device__ __forceinline__ uint32_t diff_clip(uint32_t a, uint32_t b, s16x2 lo, s16x2 hi, s16x2 off) {
+  s16x2 d = __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b);
+  d = __builtin_elementwise_min(__builtin_elementwise_max(d, lo), hi) + off;
+  return __builtin_bit_cast(uint32_t, d);
 }
 
 // Each thread produces a 16-pixel x PF_ROWS-row tile: PF_ROWS + 2 source row pieces are loaded once and every
@@ -47,7 +53,9 @@ constexpr int PF_ROWS = 4;
 // grid: x = ceil(ceil(H/PF_ROWS)*ceil(W/16)/256), y = 2*n (image index: even = left, odd = right)
 __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                         uint8_t* __restrict__ pf_l, uint8_t* __restrict__ pf_r, int W, int H,
-                                                        int pitch, int padl, size_t sstride, size_t plane, PfMap m) {
+                                                        int pitch, int padl, size_t sstride, size_t plane, size_t extent_l,
+                                                        size_t extent_r,
+                                                        PfMap m) {
   // threads are flattened over (row group, 16-pixel piece) of one image so that every lane has work whatever the width
   const int npiece = (W + 15) / 16;
   const int ngroup = (H + PF_ROWS - 1) / PF_ROWS;
@@ -59,7 +67,14 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
   const int img = blockIdx.y >> 1;
   const uint8_t* src = ((blockIdx.y & 1) ? right : left) + (size_t)img * sstride;
   uint8_t* dst0 = ((blockIdx.y & 1) ? pf_r : pf_l) + img * plane + padl + x0;
-  const bool interior = x0 >= 16 && x0 + 32 <= W;
+  // Row pieces at the image edges read a few bytes of the neighbouring row (or image) instead of taking a clamped,
+  // divergent path: those bytes only feed the forced edge columns. Only a piece whose 20-byte window would leave the
+  // caller's buffer (`extent` bytes from the side's base pointer: first row of the first image, last row of the last
+  // one) assembles its window byte by byte.
+  const size_t ioff = (size_t)img * sstride;
+  const long lo = (long)ioff + (long)(y0 > 0 ? y0 - 1 : 0) * W + x0 - 1;
+  const long hi = (long)ioff + (long)(y0 + PF_ROWS < H ? y0 + PF_ROWS : H - 1) * W + x0 + 19;
+  const bool interior = lo >= 0 && hi <= (long)((blockIdx.y & 1) ? extent_r : extent_l);
 
   // packed pieces of source rows y0-1 .. y0+PF_ROWS (reflect-101 at the image border): bytes x0-1 .. x0+18
   uint32_t rw[PF_ROWS + 2][5];
@@ -87,6 +102,20 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
     }
   }
 
+  // unpack every source row piece once: E[k][w] = columns (4w, 4w+2), O[k][w] = columns (4w+1, 4w+3) of the piece,
+  // as packed u16 pairs (column index relative to x0-1)
+  uint32_t E[PF_ROWS + 2][5], O[PF_ROWS + 2][5];
+#pragma unroll
+  for (int k = 0; k < PF_ROWS + 2; k++)
+#pragma unroll
+    for (int w = 0; w < 5; w++) {
+      E[k][w] = even_bytes(rw[k][w]);
+      O[k][w] = odd_bytes(rw[k][w]);
+    }
+  const s16x2 vlo = {(short)m.lo, (short)m.lo}, vhi = {(short)m.hi, (short)m.hi};
+  const s16x2 voff = {(short)(m.off + m.bias), (short)(m.off + m.bias)};
+  const uint32_t edge = (uint32_t)(m.off + m.bias);
+
 #pragma unroll
   for (int j = 0; j < PF_ROWS; j++) {
     const int y = y0 + j;
@@ -95,26 +124,27 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
     if (m.rtl ? (y == 0 || y == H - 1) : ((H & 1) && y == H - 1)) {
       out[0] = out[1] = out[2] = out[3] = (uint32_t)((m.rtl ? 0 : m.off) + m.bias) * 0x01010101u;
     } else {
-      int s[18];  // vertical 1-2-1 sums of columns x0-1 .. x0+16
+      // vertical 1-2-1 sums (max 4*255: no carry between the halves), then the horizontal difference
+      // s[i+2] - s[i] on packed pairs: pixels (4q, 4q+2) from the even sums, (4q+1, 4q+3) from the odd sums
+      uint32_t SE[5], SO[5];
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        uint32_t ev, od;
-        vsum4(rw[j][k], rw[j + 1][k], rw[j + 2][k], ev, od);
-        if (4 * k + 0 < 18) s[4 * k + 0] = (int)(ev & 0xffffu);
-        if (4 * k + 1 < 18) s[4 * k + 1] = (int)(od & 0xffffu);
-        if (4 * k + 2 < 18) s[4 * k + 2] = (int)(ev >> 16);
-        if (4 * k + 3 < 18) s[4 * k + 3] = (int)(od >> 16);
+      for (int w = 0; w < 5; w++) {
+        SE[w] = E[j][w] + 2u * E[j + 1][w] + E[j + 2][w];
+        SO[w] = O[j][w] + 2u * O[j + 1][w] + O[j + 2][w];
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t o = 0;
+      for (int q = 0; q < 4; q++) {
+        const uint32_t pe = diff_clip(__builtin_amdgcn_alignbit(SE[q + 1], SE[q], 16), SE[q], vlo, vhi, voff);
+        const uint32_t po = diff_clip(__builtin_amdgcn_alignbit(SO[q + 1], SO[q], 16), SO[q], vlo, vhi, voff);
+        out[q] = pe | (po << 8);
+      }
+      // image columns 0 and W-1 carry the offset value
+      if (x0 == 0) out[0] = (out[0] & 0xffffff00u) | edge;
+      const int xl = W - 1 - x0;
+      if (xl >= 0 && xl < 16) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int x = x0 + 4 * k + i;
-          const int v = (x == 0 || x >= W - 1) ? m.off : clipmap(s[4 * k + i + 2] - s[4 * k + i], m);
-          o |= (uint32_t)(v + m.bias) << (8 * i);
-        }
-        out[k] = o;
+        for (int q = 0; q < 4; q++)
+          if ((xl >> 2) == q) out[q] = (out[q] & ~(0xffu << (8 * (xl & 3)))) | (edge << (8 * (xl & 3)));
       }
     }
     uint8_t* dst = dst0 + (size_t)y * pitch;
@@ -125,8 +155,25 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
         const uint4 o4 = make_uint4(out[0], out[1], out[2], out[3]);
         __builtin_memcpy(dst, &o4, 16);                                                // dense caller-owned plane
       }
+    } else if (pitch >= padl + x0 + 16) {
+      // engine planes: the bytes right of column W-1 are padding that must read as 0 (the masked value of the SAD kernel)
+      const int nb = W - x0;  // 1..15 valid bytes
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = nb - 4 * q;
+        out[q] = r >= 4 ? out[q] : (r <= 0 ? 0u : (out[q] & (0xffffffffu >> (8 * (4 - r)))));
+      }
+      *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
     } else {
-      for (int i = 0; x0 + i < W; i++) dst[i] = (uint8_t)(out[i >> 2] >> (8 * (i & 3)));
+      // dense plane, 1..15 valid bytes: at most four partial stores (8 + 4 + 2 + 1)
+      const int nb = W - x0;
+      int q = 0;
+      uint8_t* d = dst;
+      if (nb & 8) { const uint2 o2 = make_uint2(out[0], out[1]); __builtin_memcpy(d, &o2, 8); d += 8; q = 2; }
+      if (nb & 4) { const uint32_t o1 = q ? out[2] : out[0]; __builtin_memcpy(d, &o1, 4); d += 4; q++; }
+      const uint32_t rest = q == 0 ? out[0] : (q == 1 ? out[1] : (q == 2 ? out[2] : out[3]));
+      if (nb & 2) { const uint16_t o16 = (uint16_t)rest; __builtin_memcpy(d, &o16, 2); d += 2; }
+      if (nb & 1) *d = (uint8_t)((nb & 2) ? (rest >> 16) : rest);
     }
   }
 }
@@ -138,7 +185,7 @@ hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8
   dim3 grid((npiece * ngroup + 255) / 256, 2 * g.n);
   const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0};
   hipLaunchKernelGGL(prefilter_kernel, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl,
-                     (size_t)g.W * g.H, (size_t)g.plane, m);
+                     (size_t)g.W * g.H, (size_t)g.plane, (size_t)g.n * g.W * g.H, (size_t)g.n * g.W * g.H, m);
   return hipGetLastError();
 }
 
@@ -154,11 +201,11 @@ hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, i
   const unsigned gx = (unsigned)((npiece * ngroup + 255) / 256);
   if (n >= 2)
     hipLaunchKernelGGL(prefilter_kernel, dim3(gx, 2 * (n / 2)), dim3(256), 0, s, d_src, d_src + img, d_dst, d_dst + img,
-                       W, H, W, 0, 2 * img, 2 * img, m);
+                       W, H, W, 0, 2 * img, 2 * img, (size_t)(n & ~1) * img, (size_t)(n & ~1) * img - img, m);
   if (n & 1) {
     const size_t o = (size_t)(n - 1) * img;
     hipLaunchKernelGGL(prefilter_kernel, dim3(gx, 1), dim3(256), 0, s, d_src + o, d_src + o, d_dst + o, d_dst + o, W, H, W,
-                       0, img, img, m);
+                       0, img, img, img, img, m);
   }
   return hipGetLastError();
 }
