@@ -184,12 +184,17 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 //              is already known to exceed maxSpeckleSize (saturating: exact where it matters, no contention).
 //   4. apply   heads look up their component size; the decision is broadcast along the run; small -> newVal.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int uf_find(const int* L, int i) {
+// find with path halving: a visited node is re-pointed at its grandparent with a fire-and-forget atomicMin (parents only
+// ever move towards the root, so concurrent hooks are never undone)
+__device__ __forceinline__ int uf_find(int* L, int i) {
   int r = i;
   for (;;) {
     const int p = __hip_atomic_load(L + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == r) return r;
-    r = p;
+    const int gp = __hip_atomic_load(L + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp == p) return p;
+    __hip_atomic_fetch_min(L + r, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r = gp;
   }
 }
 
@@ -322,13 +327,13 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
   }
 }
 
-__global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __restrict__ disp, const int* __restrict__ labels,
+__global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
                                                              int* __restrict__ counts, int W, int H, int newval,
                                                              int maxdiff, int maxsize) {
   SPK_ROW_SETUP
   if (y >= H) return;
   const int16_t* d = disp + plane_off + (size_t)y * W;
-  const int* L = labels + plane_off;
+  int* L = labels + plane_off;
   int* C = counts + plane_off;
   RowWalk rw;
   rw.init(newval);
@@ -345,8 +350,12 @@ __global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __res
       if (head) {
         const int self = y * W + cb + lane;
         const int r = uf_root_final(L, self);
-        if (r != self && __hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize)
-          atomicAdd(C + r, C[self]);
+        if (r != self) {
+          // parents are final: point straight at the root (any ancestor is a valid parent for concurrent readers),
+          // so the apply kernel's lookup is one step
+          L[self] = r;
+          if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, C[self]);
+        }
       }
     }
   }
