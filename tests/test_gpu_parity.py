@@ -210,6 +210,15 @@ def test_device_entry_point_matches_host_entry_point(torch_cuda, pkg, oracle):
     big[:, :640] = L[0]
     one = bm.compute(big[:, :640], np.ascontiguousarray(R[0]))
     assert np.array_equal(one, host[0])
+    # strided output (a cv::Mat ROI view): rows land at the caller's step, the padding is untouched
+    obig = np.full((200, 700), 1234, np.int16)
+    bm.compute(L[0], R[0], obig[:, 30:670])
+    assert np.array_equal(obig[:, 30:670], host[0]) and (obig[:, :30] == 1234).all() and (obig[:, 670:] == 1234).all()
+    # odd width (1-D copies of rows that are not multiples of 4 bytes), dense batch
+    L2, R2 = synth.make_batch(9, 2, 333, 64, 32)
+    bm2 = pkg.StereoBM.create(32, 9)
+    h2 = bm2.compute(L2, R2)
+    assert np.array_equal(h2, bm2.compute(torch.from_numpy(L2).cuda(), torch.from_numpy(R2).cuda()).cpu().numpy())
 
 
 def test_degenerate_and_error_behaviour(torch_cuda, pkg, oracle):
