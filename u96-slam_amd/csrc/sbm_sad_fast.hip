@@ -448,6 +448,9 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   int nseg = 1;
   static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 9000L; }();
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
+  // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
+  // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
+  while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= g.wsz && nseg < 32) nseg++;
   static const int nseg_env = [] { const char* e = getenv("SBM_FAST_NSEG"); return e ? atoi(e) : 0; }();
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
   // taper: the last third of the rows is cut into segments of 2/3, 1/2, 1/3 ... of the regular length
