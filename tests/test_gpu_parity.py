@@ -126,6 +126,17 @@ SMALL_CASES = [
     (70, 500, dict(num_disparities=208, block_size=21, min_disparity=-16, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)),
     (90, 470, dict(num_disparities=144, block_size=27, texture_threshold=0, uniqueness_ratio=0, disp12_max_diff=1)),
     (40, 330, dict(num_disparities=80, block_size=15, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    # windows that are not multiples of 3: 1-column vertical sums, w partners in the horizontal exchange
+    (40, 200, dict(num_disparities=64, block_size=5, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (44, 210, dict(num_disparities=32, block_size=7, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1,
+                   speckle_window_size=30, speckle_range=16)),
+    (50, 300, dict(num_disparities=128, block_size=11, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (52, 310, dict(num_disparities=96, block_size=13, min_disparity=-5, texture_threshold=5, uniqueness_ratio=10, disp12_max_diff=2)),
+    (60, 420, dict(num_disparities=192, block_size=17, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (66, 330, dict(num_disparities=64, block_size=19, prefilter_cap=63, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1)),
+    (70, 350, dict(num_disparities=48, block_size=23, texture_threshold=0, uniqueness_ratio=0, disp12_max_diff=1)),
+    (80, 560, dict(num_disparities=256, block_size=25, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=1,
+                   speckle_window_size=50, speckle_range=32)),
 ]
 
 

@@ -478,24 +478,22 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
                        (size_t)2 * NVC * 4 + (size_t)3 * 2 * g.w2 * 4 + (size_t)2 * 2 * 2 * NVC + 16;
     dim3 grid2(nseg, g.n);
     dim3 block2(64 * ((2 * nq + 63) / 64));
-    switch (g.w2) {
-      case 4: hipLaunchKernelGGL(sad_border2_kernel<4>, grid2, block2, lds, s, a); break;
-      case 7: hipLaunchKernelGGL(sad_border2_kernel<7>, grid2, block2, lds, s, a); break;
-      case 10: hipLaunchKernelGGL(sad_border2_kernel<10>, grid2, block2, lds, s, a); break;
-      case 13: hipLaunchKernelGGL(sad_border2_kernel<13>, grid2, block2, lds, s, a); break;
+#define SBM_B2(W) case W: hipLaunchKernelGGL(sad_border2_kernel<W>, grid2, block2, lds, s, a); break;
+    switch (g.w2) {   // every odd window 5..27
+      SBM_B2(2) SBM_B2(3) SBM_B2(4) SBM_B2(5) SBM_B2(6) SBM_B2(7) SBM_B2(8) SBM_B2(9) SBM_B2(10) SBM_B2(11) SBM_B2(12) SBM_B2(13)
       default: return hipErrorInvalidValue;
     }
+#undef SBM_B2
     return hipGetLastError();
   }
   dim3 grid(2 * nseg, g.n);
   dim3 block(64 * ((g.nd + 63) / 64));
+#define SBM_B1(W) case W: hipLaunchKernelGGL(sad_border_kernel<W>, grid, block, 0, s, a); break;
   switch (g.w2) {
-    case 4: hipLaunchKernelGGL(sad_border_kernel<4>, grid, block, 0, s, a); break;
-    case 7: hipLaunchKernelGGL(sad_border_kernel<7>, grid, block, 0, s, a); break;
-    case 10: hipLaunchKernelGGL(sad_border_kernel<10>, grid, block, 0, s, a); break;
-    case 13: hipLaunchKernelGGL(sad_border_kernel<13>, grid, block, 0, s, a); break;
+    SBM_B1(2) SBM_B1(3) SBM_B1(4) SBM_B1(5) SBM_B1(6) SBM_B1(7) SBM_B1(8) SBM_B1(9) SBM_B1(10) SBM_B1(11) SBM_B1(12) SBM_B1(13)
     default: return hipErrorInvalidValue;
   }
+#undef SBM_B1
   return hipGetLastError();
 }
 

@@ -21,7 +21,8 @@
 //   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan),
 //               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree; per-wavefront
 //               results merged through LDS, one wavefront (alternating per row) finishes and stores.
-// Envelope (checked on the host, everything else takes the generic kernel): w in {9,15,21,27}, nd <= 256,
+// Windows that are not multiples of 3 use 1-column sums (template parameter PW = 1: single-byte pattern, w-1 partners).
+// Envelope (checked on the host, everything else takes the generic kernel): odd w in 5..27, nd <= 256,
 // w*w*2*cap <= 65534 (16-bit sums), 2*(maxS*uniq/100+1) < 65535, valid-ROI rows inside [w/2, H-w/2).
 #include <stdlib.h>
 
@@ -74,18 +75,19 @@ extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NS
 // NDW disparities per wavefront, NWAVES wavefronts per workgroup covering NDW*NWAVES >= nd disparities of the SAME
 // 64 columns.  NWAVES > 1 keeps the register footprint of a wavefront at NDW/2 accumulators + NDW/2 sums (4 waves per
 // SIMD at NDW = 64) at the price of two workgroup barriers per row for the WTA merge through LDS.
-template <int NDW, int NWAVES, int NTERM, bool EXACT_ND>
+template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND>
 __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
   constexpr int NR = NDW / 2;           // packed pair registers
   constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
   constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   constexpr int NIT = NSLOT / 64;
-  constexpr int WSZ = 3 * NTERM, W2 = WSZ / 2;
-  constexpr int NV = 64 - (WSZ - 3);    // lanes that produce an output
+  // PW = columns per vertical sum (the mqsad pattern width): 3 when the window is a multiple of 3, else 1
+  constexpr int WSZ = PW * NTERM, W2 = WSZ / 2;
+  constexpr int NV = 64 - (WSZ - PW);   // lanes that produce an output
   // horizontal exchange through LDS: XCH quads at a time, XS u64 entries per quad (64 lanes + the 3*(NTERM-1) halo)
   constexpr int XCH = NQ < 8 ? NQ : 8;
-  constexpr int XS = 64 + 3 * (NTERM - 1);
+  constexpr int XS = 64 + PW * (NTERM - 1);
   constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
 
   const int lane = threadIdx.x & 63;
@@ -162,8 +164,9 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   auto apply = [&](const RowRegs& g, const int mode) {
 #pragma unroll
     for (int it = 0; it < NIT; it++) stage_lds[it * 64 + lane] = g.r[it];
-    const u32 pat = g.l & 0x00ffffffu;  // byte 3 = 0 -> masked by mqsad
-    const u32 tv = __builtin_amdgcn_sad_u8(pat | ((u32)a.capb << 24), capw, 0u);
+    constexpr u32 PMASK = PW == 3 ? 0x00ffffffu : 0x000000ffu;
+    const u32 pat = g.l & PMASK;  // remaining bytes = 0 -> masked by mqsad
+    const u32 tv = __builtin_amdgcn_sad_u8(pat | (capw & ~PMASK), capw, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // 16 quads (64 disparities) at a time: 5 + 5 ds_read_b128 cover their 17 window dwords in both alignments.
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
         u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
 #pragma unroll
         for (int k = 1; k < NTERM; k++) {
-          const uint4 r = xq[(qq / 2) * XS + lane + 3 * k];
+          const uint4 r = xq[(qq / 2) * XS + lane + PW * k];
           s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
           s1 += r.y;
           s2 += r.z;
@@ -349,7 +352,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
     if (mine) {
       int tsum = (int)Vt;
 #pragma unroll
-      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + 3 * k];
+      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + PW * k];
       bool ok = tsum >= a.tex;
       // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
       if (a.uniq > 0) {
@@ -389,7 +392,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
 }
 
 bool sad_fast_supported(const Geom& g) {
-  if (g.wsz != 9 && g.wsz != 15 && g.wsz != 21 && g.wsz != 27) return false;
+  if (g.wsz < 5 || g.wsz > 27) return false;   // every odd window 5..27: multiples of 3 with 3-column sums, the rest 1-column
   if (g.nd > 256) return false;
   const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
   if (maxs > 65534) return false;
@@ -400,30 +403,33 @@ bool sad_fast_supported(const Geom& g) {
   return true;
 }
 
-template <int NDW, int NWAVES, int NTERM>
+template <int NDW, int NWAVES, int NTERM, int PW>
 static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
   constexpr int NCH = (NDW / 4 + 15) / 16;
   constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   constexpr int NQ = NDW / 4, XCH = NQ < 8 ? NQ : 8;
-  constexpr int XS = 64 + 3 * (NTERM - 1);
+  constexpr int XS = 64 + PW * (NTERM - 1);
   constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
   constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
   const size_t lds = (size_t)NWAVES * WSLOT * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   if (a.nd == NDW * NWAVES)
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, true>), grid, dim3(64 * NWAVES), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true>), grid, dim3(64 * NWAVES), lds, s, a);
   else
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, false>), grid, dim3(64 * NWAVES), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, false>), grid, dim3(64 * NWAVES), lds, s, a);
   return hipGetLastError();
 }
 
 // mode 0 (default): 64 disparities per wavefront, nd/64 cooperating wavefronts.  mode 1: one wavefront holds all
 // (<= 128) disparities -- kept for A/B measurements (env SBM_FAST_MODE=1).
-template <int NTERM>
+template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, hipStream_t s) {
-  if (a.nd <= 32) return launch_t<32, 1, NTERM>(a, grid, s);
-  if (a.nd <= 64) return launch_t<64, 1, NTERM>(a, grid, s);
-  if (a.nd <= 128) return mode == 1 ? launch_t<128, 1, NTERM>(a, grid, s) : launch_t<64, 2, NTERM>(a, grid, s);
-  return launch_t<64, 4, NTERM>(a, grid, s);
+  if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, grid, s);
+  if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, grid, s);
+  if constexpr (PW == 3) {
+    if (a.nd <= 128 && mode == 1) return launch_t<128, 1, NTERM, PW>(a, grid, s);
+  }
+  if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, grid, s);
+  return launch_t<64, 4, NTERM, PW>(a, grid, s);
 }
 
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
@@ -439,8 +445,8 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   a.row0 = g.row0; a.row1 = g.row1;
   const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
   a.xc0 = g.w2; a.xc1 = xhi - g.w2 + 1;
-  const int nterm = g.wsz / 3;
-  const int nv = 64 - (g.wsz - 3);
+  const int pw = g.wsz % 3 == 0 ? 3 : 1;
+  const int nv = 64 - (g.wsz - pw);
   const int strips = (a.xc1 - a.xc0 + nv - 1) / nv;
   const int rows = g.row1 - g.row0;
   // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
@@ -476,11 +482,19 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   a.strips = strips; a.nseg = nseg; a.npairs = g.n;
   dim3 grid((unsigned)strips * nseg * g.n);
   hipError_t e;
-  switch (nterm) {
-    case 3: e = launch_nd<3>(a, grid, mode, s); break;
-    case 5: e = launch_nd<5>(a, grid, mode, s); break;
-    case 7: e = launch_nd<7>(a, grid, mode, s); break;
-    default: e = launch_nd<9>(a, grid, mode, s); break;
+  switch (g.wsz) {
+    case 9: e = launch_nd<3, 3>(a, grid, mode, s); break;
+    case 15: e = launch_nd<5, 3>(a, grid, mode, s); break;
+    case 21: e = launch_nd<7, 3>(a, grid, mode, s); break;
+    case 27: e = launch_nd<9, 3>(a, grid, mode, s); break;
+    case 5: e = launch_nd<5, 1>(a, grid, mode, s); break;
+    case 7: e = launch_nd<7, 1>(a, grid, mode, s); break;
+    case 11: e = launch_nd<11, 1>(a, grid, mode, s); break;
+    case 13: e = launch_nd<13, 1>(a, grid, mode, s); break;
+    case 17: e = launch_nd<17, 1>(a, grid, mode, s); break;
+    case 19: e = launch_nd<19, 1>(a, grid, mode, s); break;
+    case 23: e = launch_nd<23, 1>(a, grid, mode, s); break;
+    default: e = launch_nd<25, 1>(a, grid, mode, s); break;
   }
   *xa = a.xc0; *xb = a.xc1;
   return e;
