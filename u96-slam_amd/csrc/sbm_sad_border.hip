@@ -218,9 +218,11 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
   int* Hit = Tsum + 2 * W2;                                                   // [side][W2]
   unsigned char* Lb = reinterpret_cast<unsigned char*>(Hit + 2 * W2);         // [par][which][side][NVC]
 
-  const bool act = tid < 2 * nq;
-  const int side = act ? tid / nq : 0;
-  const int q = act ? tid - side * nq : 0;
+  // lanes 0..nq-1 = left side, lanes 32..32+nq-1 = right side (nq <= 32, one wavefront): the per-side WTA is a 32-lane
+  // butterfly whatever the disparity count
+  const int side = (tid >> 5) & 1;
+  const int q = tid & 31;
+  const bool act = tid < 64 && q < nq;
   const int ys = a.row0 + blockIdx.x * a.seg;
   const int ye = min(ys + a.seg, a.row1);
   const int pair = blockIdx.y;
@@ -338,7 +340,6 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
     accumulate(par, 0, 2);
     par ^= 1;
   }
-  if (tid < 2 * W2) Hit[tid] = 0;
 
   Staged gl = fetch(ys - W2);       // leaving row of the first output row
   for (int y = ys; y < ye; y++) {
@@ -351,8 +352,10 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
     }
     accumulate(par, 0, 0);          // CB = window rows y-W2 .. y+W2
 
-    // sliding sums over the virtual columns -> W2 outputs, 4 disparities each; publish sums and the local best key
+    // sliding sums over the virtual columns -> W2 outputs, 4 disparities each; publish the sums (sub-pixel lookup) and
+    // reduce the best key over the side's 32 lanes in registers (DPP butterfly + one cross-row exchange)
     u64 S[W2];
+    unsigned bestk[W2];
     if (act) {
       unsigned lo = 0, hi = 0;
 #pragma unroll
@@ -364,54 +367,63 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
         const unsigned d0 = 4u * q;
         const unsigned k0 = (lo << 16) | d0, k1 = (lo & 0xffff0000u) | (d0 + 1);
         const unsigned k2 = (hi << 16) | (d0 + 2), k3 = (hi & 0xffff0000u) | (d0 + 3);
-        Kb[(side * W2 + j) * nq + q] = min(min(k0, k1), min(k2, k3));
+        bestk[j] = min(min(k0, k1), min(k2, k3));
         if (j + 1 < W2) {
           lo += (unsigned)CB[j + WSZ] - (unsigned)CB[j];
           hi += (unsigned)(CB[j + WSZ] >> 32) - (unsigned)(CB[j] >> 32);
         }
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < W2; j++) { S[j] = ~0ull; bestk[j] = 0xffffffffu; }
+    }
+#pragma unroll
+    for (int j = 0; j < W2; j++) {
+      unsigned b = bestk[j];
+      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x141, 0xf, 0xf, true));  // row_half_mirror
+      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x140, 0xf, 0xf, true));  // row_mirror
+      b = min(b, (unsigned)__shfl_xor((int)b, 16, 64));                               // the other 16-lane row of the side
+      bestk[j] = b;
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
       if (e < 2 * NVC) Tc[e] = Ct[k];
     }
-    __syncthreads();
-    if (tid < 2 * W2) {             // one lane per (side, output column): reduce the quads' local bests
-      const int sd = tid / W2, j = tid - sd * W2;
-      unsigned best = 0xffffffffu;
-      for (int qq = 0; qq < nq; qq++) best = min(best, Kb[(sd * W2 + j) * nq + qq]);
-      Best[tid] = best;
-      int ts = 0;
-      for (int v = 0; v < WSZ; v++) ts += Tc[sd * NVC + j + v];
-      Tsum[tid] = ts;
-    }
-    __syncthreads();
-    if (act && a.uniq > 0) {
+    // uniqueness: any disparity of the side outside mind-1..mind+1 at or below the threshold (ballot, no LDS round trip)
 #pragma unroll
-      for (int j = 0; j < W2; j++) {
-        const unsigned best = Best[side * W2 + j];
+    for (int j = 0; j < W2; j++) {
+      const unsigned best = bestk[j];
+      bool hit = false;
+      if (act && a.uniq > 0) {
         const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
         const int thresh = minsad + (minsad * a.uniq / 100);
-        bool hit = false;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int d = 4 * q + i;
           const int sv = (int)((S[j] >> (16 * i)) & 0xffffu);
           hit |= (d < mind - 1 || d > mind + 1) && sv <= thresh;
         }
-        if (hit) Hit[side * W2 + j] = 1;
+      }
+      const unsigned long long hb = __ballot(hit);
+      if (q == 0 && tid < 64) {
+        Best[side * W2 + j] = best;
+        Hit[side * W2 + j] = (int)(((hb >> (32 * side)) & 0xffffffffull) != 0ull);
       }
     }
     accumulate(par, 1, 1);          // CA = CB - leaving row (independent of the WTA merge; overlaps its latency)
     par ^= 1;
     __syncthreads();
-    if (tid < 2 * W2) {
+    if (tid < 2 * W2) {             // one lane per (side, output column)
       const int sd = tid / W2, j = tid - sd * W2;
       const unsigned best = Best[tid];
       const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
-      const bool ok = Tsum[tid] >= a.tex && Hit[tid] == 0;
-      Hit[tid] = 0;
+      int ts = 0;
+#pragma unroll
+      for (int v = 0; v < WSZ; v++) ts += Tc[sd * NVC + j + v];
+      const bool ok = ts >= a.tex && Hit[tid] == 0;
       int out = a.filtered;
       const size_t o = (size_t)pair * a.W * a.H + (size_t)y * a.W + a.lofs + a.xo[sd] + j;
       if (ok) {
@@ -428,7 +440,7 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       }
       a.disp[o] = (int16_t)out;
     }
-    // the next iteration's first __syncthreads orders the reuse of Sb/Kb/Tc/Best/Tsum; Hit was reset by its reader
+    // the next iteration's first __syncthreads orders the reuse of Sb/Tc/Best/Hit
   }
 }
 
@@ -454,7 +466,7 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   static const int version_env = [] { const char* e = getenv("SBM_BORDER_V"); return e ? atoi(e) : 0; }();
   // quad-per-lane kernel up to 128 disparities (one wavefront per workgroup); beyond that its two-wavefront workgroups
   // with 256 VGPRs become the tail of the step (measured at 1080p nd256: 3.75 vs 3.64 ms) -> per-disparity kernel
-  const int version = version_env ? version_env : (g.nd <= 128 ? 2 : 1);
+  const int version = g.nd > 128 ? 1 : (version_env ? version_env : 2);   // the quad kernel maps one side to 32 lanes
   int seg_rows = seg_rows_env;
   if (seg_rows <= 0) {
     if (version != 1) {
