@@ -217,27 +217,44 @@ __device__ __forceinline__ int uf_root_final(const int* L, int i) {
   return r;
 }
 
-// Walks one row left to right. For the 64-pixel chunk at `cb` returns, per lane: value v, valid, head and the column
-// where the lane's run starts. State carried across chunks: prev_last (value left of the chunk), carry (run start of
-// the pixel left of the chunk, -1 if it is invalid).
+// Walks one row left to right in 64-pixel chunks. The per-chunk state lives in wavefront-uniform 64-bit masks (valid
+// pixels, run heads) that cost a handful of compares plus scalar mask algebra; the per-lane "column where my run
+// starts" -- the expensive part -- is only computed on demand (start()), i.e. in the few chunks where a kernel has
+// something to do (a vertical contact, a run to erase). State carried across chunks: prev_last (value left of the
+// chunk), prev_valid, carry (run start of the pixel left of the chunk, -1 if it is invalid).
 struct RowWalk {
-  int prev_last, carry;
-  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; }
-  __device__ __forceinline__ void step(int v, int cb, int lane, int newval, int maxdiff, bool& valid, bool& head,
-                                       int& start) {
+  int prev_last, carry, cb;
+  bool prev_valid;
+  unsigned long long valid, head;   // uniform
+  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; prev_valid = false; }
+  // masks of the chunk at column cb_ (lanes beyond the row hold newval = invalid)
+  __device__ __forceinline__ void step(int v, int cb_, int lane, int newval, int maxdiff) {
+    cb = cb_;
     int pv = __shfl_up(v, 1, 64);
     if (lane == 0) pv = prev_last;
-    valid = v != newval;
-    head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
-    const unsigned long long m = __ballot(head) & ((2ull << lane) - 1ull);
-    start = m ? cb + (63 - __clzll((long long)m)) : carry;
-    carry = __shfl(valid ? start : -1, 63, 64);
+    valid = __ballot(v != newval);
+    const unsigned long long closem = __ballot(abs(v - pv) <= maxdiff);
+    const unsigned long long pvalid = (valid << 1) | (prev_valid ? 1ull : 0ull);
+    head = valid & ~(pvalid & closem);
+  }
+  // column where the lane's run starts (meaningful for valid lanes)
+  __device__ __forceinline__ int start(int lane) const {
+    const unsigned long long m = head & ((2ull << lane) - 1ull);
+    return m ? cb + (63 - __clzll((long long)m)) : carry;
+  }
+  // advance the carried state to the next chunk (uniform arithmetic only)
+  __device__ __forceinline__ void next(int v) {
+    const bool v63 = (valid >> 63) & 1ull;
+    carry = v63 ? (head ? cb + (63 - __clzll((long long)head)) : carry) : -1;
+    prev_valid = v63;
     prev_last = __shfl(v, 63, 64);
   }
+  // bit position (0..63) of the head of the run that contains pixel 63 of this chunk, -1 if that run started earlier
+  __device__ __forceinline__ int last_head_bit() const { return head ? 63 - __clzll((long long)head) : -1; }
 };
 
 // Rows are walked in groups of SPK_G chunks whose values are loaded up front (SPK_G independent loads in flight per
-// lane) -- the walk itself is a serial chain of ballots, so without this every chunk would pay a full memory latency.
+// lane) -- the walk itself is a serial chain, so without this every chunk would pay a full memory latency.
 constexpr int SPK_G = 8;
 __device__ __forceinline__ void spk_load_group(const int16_t* d, int cb0, int W, int lane, int newval, int (&v)[SPK_G]) {
 #pragma unroll
@@ -281,25 +298,45 @@ __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __rest
       if (lane == 0) pv = left;
       const bool valid = v != newval;
       const bool head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
-      const unsigned long long bm = __ballot(!valid || head);  // lanes beyond W count as invalid = boundary
-      const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
-      const int nb = above ? x + __ffsll((long long)above) : next_b;
-      if (head) {
-        L[y * W + x] = y * W + x;
-        C[y * W + x] = nb - x;
+      const unsigned long long hm = __ballot(head);
+      const unsigned long long bm = hm | ~__ballot(valid);     // lanes beyond W count as invalid = boundary
+      if (hm) {                                                // uniform: most chunks hold no run head
+        const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
+        const int nb = above ? x + __ffsll((long long)above) : next_b;
+        if (head) {
+          L[y * W + x] = y * W + x;
+          C[y * W + x] = nb - x;
+        }
       }
       if (bm) next_b = cb + __ffsll((long long)bm) - 1;
     }
   }
 }
 
+// The row walk only COLLECTS the contacts (pairs of run heads) into a wavefront-private LDS list; the unions -- chains
+// of dependent L2 round trips -- then run 64 at a time. Doing them inside the walk made every 64-pixel chunk that holds
+// a contact pay a full union latency with one or two lanes busy.
+constexpr int SPK_CAP = 448;   // contacts buffered per wavefront (flushed when fewer than 64 free slots remain)
 __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
                                                              int W, int H, int newval, int maxdiff) {
+  __shared__ int2 contact_lds[4][SPK_CAP];
   SPK_ROW_SETUP
   if (y >= H - 1) return;
   const int16_t* du = disp + plane_off + (size_t)y * W;
   const int16_t* dd = du + W;
   int* L = labels + plane_off;
+  int2* const list = contact_lds[threadIdx.x >> 6];
+  int count = 0;   // uniform
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < count; i += 64) {
+      const int2 c = list[i];
+      uf_union(L, c.x, c.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    count = 0;
+  };
   RowWalk up, dn;
   up.init(newval);
   dn.init(newval);
@@ -313,82 +350,132 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
       const int cb = cb0 + 64 * g;
       if (cb >= W) break;
       const int vu = vus[g], vd = vds[g];
-      int su, sd;
-      bool valu, vald, hu, hd;
-      up.step(vu, cb, lane, newval, maxdiff, valu, hu, su);
-      dn.step(vd, cb, lane, newval, maxdiff, vald, hd, sd);
-      const bool cd = valu && vald && abs(vu - vd) <= maxdiff;
-      bool pcd = __shfl_up((int)cd, 1, 64) != 0;
-      if (lane == 0) pcd = prev_cd;
+      up.step(vu, cb, lane, newval, maxdiff);
+      dn.step(vd, cb, lane, newval, maxdiff);
+      const unsigned long long cdm = up.valid & dn.valid & __ballot(abs(vu - vd) <= maxdiff);
+      const unsigned long long pcdm = (cdm << 1) | (prev_cd ? 1ull : 0ull);
       // same two runs as the pixel to the left and that pixel already made the contact -> nothing new
-      if (cd && !(pcd && !hu && !hd)) uf_union(L, y * W + su, (y + 1) * W + sd);
-      prev_cd = __shfl((int)cd, 63, 64) != 0;
+      const unsigned long long fm = cdm & ~(pcdm & ~up.head & ~dn.head);
+      if (fm) {                                                // uniform: most chunks hold no new contact
+        if ((fm >> lane) & 1ull)
+          list[count + __popcll(fm & ((1ull << lane) - 1ull))] = make_int2(y * W + up.start(lane), (y + 1) * W + dn.start(lane));
+        count += __popcll(fm);
+        if (count > SPK_CAP - 64) flush();
+      }
+      prev_cd = (cdm >> 63) & 1ull;
+      up.next(vu);
+      dn.next(vd);
     }
   }
+  if (count) flush();
+}
+
+// count and apply work on one load group (SPK_G chunks = 512 pixels) at a time: the walk COLLECTS the group's run heads in
+// a wavefront-private LDS list, then the root / size look-ups -- dependent L2 round trips -- run 64 heads at a time
+// (one latency per group instead of one per chunk that holds a head).
+constexpr int SPK_HEADS = 64 * SPK_G;   // a pixel is at most one head
+
+__device__ __forceinline__ int spk_collect_heads(RowWalk& rw, const int (&vs)[SPK_G], int cb0, int W, int lane, int newval,
+                                                 int maxdiff, int rowbase, int* list) {
+  int nh = 0;   // uniform
+#pragma unroll
+  for (int g = 0; g < SPK_G; g++) {
+    const int cb = cb0 + 64 * g;
+    if (cb >= W) break;
+    rw.step(vs[g], cb, lane, newval, maxdiff);
+    const unsigned long long hm = rw.head;
+    if (hm) {
+      if ((hm >> lane) & 1ull) list[nh + __popcll(hm & ((1ull << lane) - 1ull))] = rowbase + cb + lane;
+      nh += __popcll(hm);
+    }
+    rw.next(vs[g]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return nh;
 }
 
 __global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
                                                              int* __restrict__ counts, int W, int H, int newval,
                                                              int maxdiff, int maxsize) {
+  __shared__ int head_lds[4][SPK_HEADS];
   SPK_ROW_SETUP
   if (y >= H) return;
   const int16_t* d = disp + plane_off + (size_t)y * W;
   int* L = labels + plane_off;
   int* C = counts + plane_off;
+  int* const list = head_lds[threadIdx.x >> 6];
   RowWalk rw;
   rw.init(newval);
   for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
     int vs[SPK_G];
     spk_load_group(d, cb0, W, lane, newval, vs);
-#pragma unroll
-    for (int g = 0; g < SPK_G; g++) {
-      const int cb = cb0 + 64 * g;
-      if (cb >= W) break;
-      int st;
-      bool valid, head;
-      rw.step(vs[g], cb, lane, newval, maxdiff, valid, head, st);
-      if (head) {
-        const int self = y * W + cb + lane;
-        const int r = uf_root_final(L, self);
-        if (r != self) {
-          // parents are final: point straight at the root (any ancestor is a valid parent for concurrent readers),
-          // so the apply kernel's lookup is one step
-          L[self] = r;
-          if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, C[self]);
-        }
+    const int nh = spk_collect_heads(rw, vs, cb0, W, lane, newval, maxdiff, y * W, list);
+    for (int i = lane; i < nh; i += 64) {
+      const int self = list[i];
+      const int r = uf_root_final(L, self);
+      if (r != self) {
+        // parents are final: point straight at the root (any ancestor is a valid parent for concurrent readers),
+        // so the apply kernel's lookup is one step
+        L[self] = r;
+        if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, C[self]);
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict__ disp, const int* __restrict__ labels,
                                                              const int* __restrict__ counts, int W, int H, int newval,
                                                              int maxdiff, int maxsize) {
+  __shared__ int head_lds[4][SPK_HEADS];
   SPK_ROW_SETUP
   if (y >= H) return;
   int16_t* d = disp + plane_off + (size_t)y * W;
   const int* L = labels + plane_off;
   const int* C = counts + plane_off;
+  int* const list = head_lds[threadIdx.x >> 6];
   RowWalk rw;
   rw.init(newval);
-  int carry_kill = 0;  // decision of the run that contains the pixel left of the chunk
+  bool carry_kill = false;  // decision of the run that contains the pixel left of the chunk (uniform)
   for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
     int vs[SPK_G];
     spk_load_group(d, cb0, W, lane, newval, vs);   // original values: the stores below never feed a later load
-#pragma unroll
-    for (int g = 0; g < SPK_G; g++) {
-      const int cb = cb0 + 64 * g;
-      if (cb >= W) break;
-      int st;
-      bool valid, head;
-      rw.step(vs[g], cb, lane, newval, maxdiff, valid, head, st);
-      int kill = 0;
-      if (head) kill = C[uf_root_final(L, y * W + cb + lane)] <= maxsize;
-      const int from = __shfl(kill, st >= cb ? st - cb : 0, 64);   // decision of this lane's run head (if in the chunk)
-      const int mine = valid ? (st >= cb ? from : carry_kill) : 0;
-      if (mine) d[cb + lane] = (int16_t)newval;
-      carry_kill = __shfl(mine, 63, 64);
+    const RowWalk at_group_start = rw;
+    const int nh = spk_collect_heads(rw, vs, cb0, W, lane, newval, maxdiff, y * W, list);
+    // decisions of the group's heads, 64 at a time; list[i] becomes 1 (speckle: erase) or 0
+    bool any = false;
+    for (int i0 = 0; i0 < nh; i0 += 64) {
+      const int i = i0 + lane;
+      bool kill = false;
+      if (i < nh) {
+        kill = C[uf_root_final(L, list[i])] <= maxsize;
+        list[i] = kill ? 1 : 0;
+      }
+      any |= __ballot(kill) != 0ull;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (any || carry_kill) {                                   // uniform: most groups have nothing to erase
+      RowWalk r2 = at_group_start;
+      int idx = 0;                                             // heads of the group before the current chunk
+#pragma unroll
+      for (int g = 0; g < SPK_G; g++) {
+        const int cb = cb0 + 64 * g;
+        if (cb >= W) break;
+        r2.step(vs[g], cb, lane, newval, maxdiff);
+        const unsigned long long hm = r2.head;
+        const int below = __popcll(hm & ((2ull << lane) - 1ull));   // heads of this chunk at or left of the lane
+        const bool mine = ((r2.valid >> lane) & 1ull) && (below ? list[idx + below - 1] != 0 : carry_kill);
+        if (mine) d[cb + lane] = (int16_t)newval;
+        const int nhc = __popcll(hm);
+        carry_kill = ((r2.valid >> 63) & 1ull) ? (nhc ? list[idx + nhc - 1] != 0 : carry_kill) : false;
+        idx += nhc;
+        r2.next(vs[g]);
+      }
+    }
+    // (nothing erased in this group and nothing carried in: the run reaching the next group is not a speckle either)
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
