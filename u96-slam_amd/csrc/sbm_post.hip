@@ -277,40 +277,39 @@ __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __rest
   SPK_ROW_SETUP
   if (y >= H) return;
   const int16_t* d = disp + plane_off + (size_t)y * W;
-  int* L = labels + plane_off;
-  int* C = counts + plane_off;
-  // right to left: every head learns the distance to the next boundary (head or invalid pixel or row end)
-  int next_b = W;
-  const int ngroups = (W + 64 * SPK_G - 1) / (64 * SPK_G);
-  for (int gi = ngroups - 1; gi >= 0; gi--) {
-    const int cb0 = gi * 64 * SPK_G;
+  int* L = labels + plane_off + (size_t)y * W;
+  int* C = counts + plane_off + (size_t)y * W;
+  // every head learns the distance to the next boundary (head, invalid pixel or row end). A run that leaves its chunk
+  // stays "open" (uniform state) and is closed by the first boundary of a later chunk.
+  RowWalk rw;
+  rw.init(newval);
+  int open_start = -1;
+  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
     int vs[SPK_G];
     spk_load_group(d, cb0, W, lane, newval, vs);
-    const int left_of_group = cb0 > 0 ? (int)d[cb0 - 1] : newval;
 #pragma unroll
-    for (int g = SPK_G - 1; g >= 0; g--) {
+    for (int g = 0; g < SPK_G; g++) {
       const int cb = cb0 + 64 * g;
-      if (cb >= W) continue;
-      const int x = cb + lane;
-      const int v = vs[g];
-      int pv = __shfl_up(v, 1, 64);
-      const int left = g > 0 ? __shfl(vs[g > 0 ? g - 1 : 0], 63, 64) : left_of_group;
-      if (lane == 0) pv = left;
-      const bool valid = v != newval;
-      const bool head = valid && !(pv != newval && abs(v - pv) <= maxdiff);
-      const unsigned long long hm = __ballot(head);
-      const unsigned long long bm = hm | ~__ballot(valid);     // lanes beyond W count as invalid = boundary
-      if (hm) {                                                // uniform: most chunks hold no run head
-        const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
-        const int nb = above ? x + __ffsll((long long)above) : next_b;
-        if (head) {
-          L[y * W + x] = y * W + x;
-          C[y * W + x] = nb - x;
-        }
+      if (cb >= W) break;
+      rw.step(vs[g], cb, lane, newval, maxdiff);
+      const unsigned long long hm = rw.head, bm = hm | ~rw.valid;   // lanes beyond W are invalid = boundary
+      if (open_start >= 0 && bm) {
+        if (lane == 0) C[open_start] = cb + (__ffsll((long long)bm) - 1) - open_start;
+        open_start = -1;
       }
-      if (bm) next_b = cb + __ffsll((long long)bm) - 1;
+      if (hm) {                                                      // uniform: most chunks hold no run head
+        if ((hm >> lane) & 1ull) {
+          const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
+          L[cb + lane] = y * W + cb + lane;
+          if (above) C[cb + lane] = __ffsll((long long)above);
+        }
+        const int hb = 63 - __clzll((long long)hm);                  // the last head stays open if nothing bounds it
+        if (hb == 63 || (bm >> (hb + 1)) == 0ull) open_start = cb + hb;
+      }
+      rw.next(vs[g]);
     }
   }
+  if (open_start >= 0 && lane == 0) C[open_start] = W - open_start;
 }
 
 // The row walk only COLLECTS the contacts (pairs of run heads) into a wavefront-private LDS list; the unions -- chains
