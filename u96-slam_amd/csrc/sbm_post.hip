@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
 // is an LDS read, and the claim key is 32 bits (cost << 16 | x) -> ds_min_u32.
 extern __shared__ __attribute__((aligned(16))) unsigned lr_lds32[];
 
-template <int NPT>
+template <int NIT>
 __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
   const int y = blockIdx.x;
   const size_t base = ((size_t)blockIdx.y * a.H + y) * a.W;
@@ -94,61 +94,89 @@ __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
     for (int x = threadIdx.x; x < a.W; x += 256) out[x] = (int16_t)a.filtered;
     return;
   }
-  unsigned* keys = lr_lds32;                                             // [W]
-  int16_t* srow = reinterpret_cast<int16_t*>(lr_lds32 + a.W);            // [W] pre-LR disparities of the row
+  unsigned* keys = lr_lds32;                                                        // [W4]
+  const int W4 = (a.W + 3) & ~3;
+  int16_t* srow = reinterpret_cast<int16_t*>(lr_lds32 + W4);                        // [W4] pre-LR disparities of the row
   const int16_t* dp = a.disp_pre + base;
   const uint16_t* cp = static_cast<const uint16_t*>(a.cost) + base;
   const int INV = a.filtered;
   const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(a.W + min(a.mindisp, 0), a.cx1);
-  int dv[NPT];
-  unsigned cv[NPT];
+  // a thread owns 4 adjacent pixels per iteration: 8-byte loads / stores (rows are only 2-byte aligned: unaligned ones)
+  int dv[NIT][4];
+  unsigned cv[NIT][4];
 #pragma unroll
-  for (int k = 0; k < NPT; k++) {
-    const int x = threadIdx.x + 256 * k;
-    const bool live = x >= a.cx0 && x < a.cx1;
-    dv[k] = live ? (int)dp[x] : INV;
-    cv[k] = (x >= minX1 && x < maxX1) ? (unsigned)cp[x] : 0u;
+  for (int k = 0; k < NIT; k++) {
+    const int x0 = 4 * (threadIdx.x + 256 * k);
+    short dd[4] = {0, 0, 0, 0};
+    unsigned short cc[4] = {0, 0, 0, 0};
+    if (x0 + 4 <= a.W) {
+      __builtin_memcpy(dd, dp + x0, 8);
+      __builtin_memcpy(cc, cp + x0, 8);
+    } else {
+      for (int i = 0; x0 + i < a.W; i++) { dd[i] = dp[x0 + i]; cc[i] = cp[x0 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int x = x0 + i;
+      dv[k][i] = (x >= a.cx0 && x < a.cx1) ? (int)dd[i] : INV;
+      cv[k][i] = (x >= minX1 && x < maxX1) ? (unsigned)cc[i] : 0u;
+    }
   }
 #pragma unroll
-  for (int k = 0; k < NPT; k++) {
-    const int x = threadIdx.x + 256 * k;
-    if (x < a.W) {
-      keys[x] = 0xffffffffu;
-      srow[x] = (int16_t)dv[k];
+  for (int k = 0; k < NIT; k++) {
+    const int x0 = 4 * (threadIdx.x + 256 * k);
+    if (x0 < W4) {
+      *reinterpret_cast<uint4*>(keys + x0) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      const unsigned lo = (unsigned)(dv[k][0] & 0xffff) | ((unsigned)dv[k][1] << 16);
+      const unsigned hi = (unsigned)(dv[k][2] & 0xffff) | ((unsigned)dv[k][3] << 16);
+      *reinterpret_cast<uint2*>(srow + x0) = make_uint2(lo, hi);
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NPT; k++) {
-    const int x = threadIdx.x + 256 * k;
-    const int d = dv[k];
-    if (x >= minX1 && x < maxX1 && d != INV) {
-      const int x2 = x - ((d + 8) >> 4);
-      if (x2 >= 0 && x2 < a.W) atomicMin(&keys[x2], (cv[k] << 16) | (unsigned)x);
+  for (int k = 0; k < NIT; k++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int x = 4 * (threadIdx.x + 256 * k) + i;
+      const int d = dv[k][i];
+      if (x >= minX1 && x < maxX1 && d != INV) {
+        const int x2 = x - ((d + 8) >> 4);
+        if (x2 >= 0 && x2 < a.W) atomicMin(&keys[x2], (cv[k][i] << 16) | (unsigned)x);
+      }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NPT; k++) {
-    const int x = threadIdx.x + 256 * k;
-    if (x >= a.W) continue;
-    int d = dv[k];
-    if (x < a.col0 || x >= a.col1) {
-      d = INV;
-    } else if (d != INV && x >= minX1 && x < maxX1) {
-      const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
-      bool bad_a = false, bad_b = false;
-      if (xa >= 0 && xa < a.W) {
-        const unsigned kk = keys[xa];
-        if (kk != 0xffffffffu) bad_a = abs((int)srow[kk & 0xffffu] - d) > a.tol;
+  for (int k = 0; k < NIT; k++) {
+    const int x0 = 4 * (threadIdx.x + 256 * k);
+    if (x0 >= a.W) continue;
+    short res[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int x = x0 + i;
+      int d = dv[k][i];
+      if (x < a.col0 || x >= a.col1) {
+        d = INV;
+      } else if (d != INV && x >= minX1 && x < maxX1) {
+        const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
+        bool bad_a = false, bad_b = false;
+        if (xa >= 0 && xa < a.W) {
+          const unsigned kk = keys[xa];
+          if (kk != 0xffffffffu) bad_a = abs((int)srow[kk & 0xffffu] - d) > a.tol;
+        }
+        if (xb >= 0 && xb < a.W) {
+          const unsigned kk = keys[xb];
+          if (kk != 0xffffffffu) bad_b = abs((int)srow[kk & 0xffffu] - d) > a.tol;
+        }
+        if (bad_a && bad_b) d = INV;
       }
-      if (xb >= 0 && xb < a.W) {
-        const unsigned kk = keys[xb];
-        if (kk != 0xffffffffu) bad_b = abs((int)srow[kk & 0xffffu] - d) > a.tol;
-      }
-      if (bad_a && bad_b) d = INV;
+      res[i] = (short)d;
     }
-    out[x] = (int16_t)d;
+    if (x0 + 4 <= a.W) {
+      __builtin_memcpy(out + x0, res, 8);
+    } else {
+      for (int i = 0; x0 + i < a.W; i++) out[x0 + i] = res[i];
+    }
   }
 }
 
@@ -160,9 +188,10 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
   a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
   a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;
   if (a.do_lr && g.cost16 && g.W <= 4096) {
-    const size_t lds16 = (size_t)g.W * 6 + 16;
-    if (g.W <= 2048) hipLaunchKernelGGL(lrcheck16_kernel<8>, dim3(g.H, g.n), dim3(256), lds16, s, a);
-    else hipLaunchKernelGGL(lrcheck16_kernel<16>, dim3(g.H, g.n), dim3(256), lds16, s, a);
+    const size_t lds16 = (size_t)((g.W + 3) & ~3) * 6 + 16;
+    if (g.W <= 1024) hipLaunchKernelGGL(lrcheck16_kernel<1>, dim3(g.H, g.n), dim3(256), lds16, s, a);
+    else if (g.W <= 2048) hipLaunchKernelGGL(lrcheck16_kernel<2>, dim3(g.H, g.n), dim3(256), lds16, s, a);
+    else hipLaunchKernelGGL(lrcheck16_kernel<4>, dim3(g.H, g.n), dim3(256), lds16, s, a);
     return hipGetLastError();
   }
   size_t lds = a.do_lr ? (size_t)g.W * sizeof(unsigned long long) : 0;
