@@ -67,6 +67,31 @@ def small_components_left(disp, win, rng_diff, filtered):
     return int(((sizes > 0) & (sizes <= win)).sum())
 
 
+def small_components_left_interior(disp, win, rng_diff, filtered):
+    """like small_components_left, ignoring components that touch the border of the array (a crop cuts them)"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    h, w = disp.shape
+    d = disp.astype(np.int32)
+    valid = d != filtered
+    idx = np.arange(h * w).reshape(h, w)
+    eh = valid[:, :-1] & valid[:, 1:] & (np.abs(d[:, :-1] - d[:, 1:]) <= rng_diff)
+    ev = valid[:-1, :] & valid[1:, :] & (np.abs(d[:-1, :] - d[1:, :]) <= rng_diff)
+    src = np.concatenate([idx[:, :-1][eh], idx[:-1, :][ev]])
+    dst = np.concatenate([idx[:, 1:][eh], idx[1:, :][ev]])
+    g = coo_matrix((np.ones(src.size, np.int8), (src, dst)), shape=(h * w, h * w))
+    _, lab = connected_components(g, directed=False)
+    lab = lab.reshape(h, w)
+    sizes = np.bincount(lab[valid], minlength=lab.max() + 1)
+    border = np.zeros_like(valid)
+    border[0, :] = border[-1, :] = border[:, 0] = border[:, -1] = True
+    touching = np.unique(lab[valid & border])
+    small = (sizes > 0) & (sizes <= win)
+    small[touching] = False
+    return int(small.sum())
+
+
 def check_common(out, W, H, nd, wsz, filtered=-16):
     # never-valid frame (cv getValidDisparityROI): left nd-1+w/2 columns, right w/2 columns, w/2 rows top and bottom
     h2 = wsz // 2
@@ -160,3 +185,28 @@ def test_shift_covariance_full_hd(torch_cuda, pkg):
     assert both.mean() > 0.5
     assert np.array_equal(b[both], a[both] + 16 * k)
     assert (np.abs(a[both].astype(int) - 40 * 16) <= 8).mean() > 0.99   # whole-pixel truth, sub-pixel term within half a pixel
+
+
+def test_very_large_frame(torch_cuda, pkg, oracle):
+    """One 8192x2048 frame (wider than the 16-bit-key LR kernel's 4096 columns, 16.8 Mpx of labels): row bands against the
+    oracle, frame and range properties, speckle post-condition on a crop."""
+    torch = torch_cuda
+    from u96_slam_amd import synth
+
+    W, H, nd, wsz = 8192, 2048, 256, 21
+    L, R = synth.make_pair(55, W, H, nd)
+    rng = np.random.default_rng(9)
+    R[H // 2:] = np.clip(R[H // 2:].astype(np.int16) + rng.integers(-48, 49, (H - H // 2, W), dtype=np.int16), 0, 255).astype(np.uint8)
+    dL, dR = torch.from_numpy(L[None]).cuda(), torch.from_numpy(R[None]).cuda()
+    out = make_engine(pkg, nd, wsz, **FULL).compute_device(dL, dR).cpu().numpy()
+    check_common(out, W, H, nd, wsz)
+    nosp = dict(FULL, speckle_window_size=0, speckle_range=0)
+    got = make_engine(pkg, nd, wsz, **nosp).compute_device(dL, dR).cpu().numpy()[0]
+    for y0 in (wsz, H // 2 - 16, H - 2 * wsz - 40):
+        band_vs_oracle(pkg, oracle, L, R, nd, wsz, y0, 32, got)
+    changed = out[0] != got
+    assert (out[0][changed] == -16).all() and changed.sum() > 0
+    # components cut by a crop border look smaller than they are, so check the crop of the FILTERED map only for components
+    # that do not touch the crop border: none of them may be small
+    crop = out[0][H // 2 + 100:H // 2 + 400, 1000:3000]
+    assert small_components_left_interior(crop, 50, 32, -16) == 0
