@@ -66,7 +66,8 @@ def main():
     # SBM_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks (ranks then
     # share devices; numbers from such a run are meaningless). The driver's runs use nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("SBM_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
+    if backend != "nccl" or local_rank >= torch.cuda.device_count():
+        # (also covers launchers that expose one device per process through HIP_VISIBLE_DEVICES)
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
