@@ -424,11 +424,13 @@ static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
 template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, hipStream_t s) {
   if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, grid, s);
+  if (a.nd == 48) return launch_t<32, 2, NTERM, PW>(a, grid, s);   // the masked single-wavefront variant needs 174 VGPRs
   if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, grid, s);
   if constexpr (PW == 3) {
     if (a.nd <= 128 && mode == 1) return launch_t<128, 1, NTERM, PW>(a, grid, s);
   }
   if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, grid, s);
+  if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, grid, s);
   return launch_t<64, 4, NTERM, PW>(a, grid, s);
 }
 
