@@ -225,6 +225,16 @@ def test_device_entry_point_matches_host_entry_point(torch_cuda, pkg, oracle):
     obig = np.full((200, 700), 1234, np.int16)
     bm.compute(L[0], R[0], obig[:, 30:670])
     assert np.array_equal(obig[:, 30:670], host[0]) and (obig[:, :30] == 1234).all() and (obig[:, 670:] == 1234).all()
+    # a dense batch large enough for the pipelined host path (chunks over copy / compute / copy streams), ragged last chunk
+    L3, R3 = synth.make_batch(20, 5, 320, 96, 32)
+    L3, R3 = np.concatenate([L3] * 4)[:19], np.concatenate([R3] * 4)[:19]
+    bm3 = pkg.StereoBM.create(32, 9)
+    bm3.setDisp12MaxDiff(1); bm3.setSpeckleWindowSize(30); bm3.setSpeckleRange(16)
+    h3 = bm3.compute(L3, R3)
+    d3 = bm3.compute(torch.from_numpy(L3).cuda(), torch.from_numpy(R3).cuda()).cpu().numpy()
+    assert np.array_equal(h3, d3)
+    for i in range(5, 19):
+        assert np.array_equal(h3[i], h3[i % 5])
     # odd width (1-D copies of rows that are not multiples of 4 bytes), dense batch
     L2, R2 = synth.make_batch(9, 2, 333, 64, 32)
     bm2 = pkg.StereoBM.create(32, 9)

@@ -33,6 +33,11 @@ struct sbm_handle {
   int16_t* st_d;
   uint8_t* pin;        // pinned host staging for strided caller images (rows packed / unpacked on the CPU)
   size_t pin_bytes;
+  // copy streams + per-chunk events of the pipelined host batch path (created on first use)
+  hipStream_t stream_in, stream_out;
+  static constexpr int kChunks = 64;
+  hipEvent_t ev_in[kChunks], ev_done[kChunks];
+  bool pipe_ok;
   // last launch (for sbm_debug_fetch)
   Geom last;
   bool have_last;
@@ -165,6 +170,13 @@ void sbm_destroy(sbm_handle* h) {
   free_staging(h);
   for (int r = 0; r < sbm_handle::kRing; r++)
     for (int i = 0; i < sbm_handle::kMarks; i++) hipEventDestroy(h->ev[r][i]);
+  if (h->pipe_ok) {
+    hipStreamSynchronize(h->stream_in);
+    hipStreamSynchronize(h->stream_out);
+    for (int i = 0; i < sbm_handle::kChunks; i++) { hipEventDestroy(h->ev_in[i]); hipEventDestroy(h->ev_done[i]); }
+    hipStreamDestroy(h->stream_in);
+    hipStreamDestroy(h->stream_out);
+  }
   hipStreamSynchronize(h->stream2);
   hipEventDestroy(h->ev_fork);
   hipEventDestroy(h->ev_join);
@@ -506,6 +518,57 @@ static int ensure_staging(sbm_handle* h, int n, int W, int H) {
   return SBM_OK;
 }
 
+static int ensure_pipe(sbm_handle* h) {
+  if (h->pipe_ok) return SBM_OK;
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking));
+  for (int i = 0; i < sbm_handle::kChunks; i++) {
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+  }
+  h->pipe_ok = true;
+  return SBM_OK;
+}
+
+// Large dense host batches: chunks of pairs flow through three streams -- H2D copies, compute, D2H copies -- so the GPU
+// works on chunk k while chunk k+1 arrives and chunk k-1 leaves. With pageable caller memory the copies themselves still
+// run one after the other on the calling thread (the runtime stages them), but the compute disappears behind them; with
+// pinned (hipHostMalloc / hipHostRegister) caller memory the two copy directions overlap as well.
+static int compute_batch_pipelined(sbm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int width,
+                                   int height, int16_t* const* disp) {
+  int st = ensure_pipe(h);
+  if (st != SBM_OK) return st;
+  const size_t npix1 = (size_t)width * height;
+  int chunk = 8;
+  while ((n + chunk - 1) / chunk > sbm_handle::kChunks) chunk *= 2;
+  const int nch = (n + chunk - 1) / chunk;
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffers of an earlier call are free
+  for (int k = 0; k < nch; k++) {
+    const int i0 = k * chunk, cnt = std::min(chunk, n - i0);
+    for (int i = i0; i < i0 + cnt; i++) {
+      HIPCHK(h, hipMemcpyAsync(h->st_l + i * npix1, left[i], npix1, hipMemcpyHostToDevice, h->stream_in));
+      HIPCHK(h, hipMemcpyAsync(h->st_r + i * npix1, right[i], npix1, hipMemcpyHostToDevice, h->stream_in));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_in[k], h->stream_in));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[k], 0));
+    st = sbm_compute_device(h, cnt, h->st_l + i0 * npix1, h->st_r + i0 * npix1, width, height, h->st_d + i0 * npix1, 0);
+    if (st != SBM_OK) return st;
+    HIPCHK(h, hipEventRecord(h->ev_done[k], h->stream));
+    if (k > 0) {   // the previous chunk leaves while this one computes
+      const int j0 = (k - 1) * chunk;
+      HIPCHK(h, hipStreamWaitEvent(h->stream_out, h->ev_done[k - 1], 0));
+      for (int i = j0; i < j0 + chunk; i++)
+        HIPCHK(h, hipMemcpyAsync(disp[i], h->st_d + i * npix1, npix1 * 2, hipMemcpyDeviceToHost, h->stream_out));
+    }
+  }
+  HIPCHK(h, hipStreamWaitEvent(h->stream_out, h->ev_done[nch - 1], 0));
+  for (int i = (nch - 1) * chunk; i < n; i++)
+    HIPCHK(h, hipMemcpyAsync(disp[i], h->st_d + i * npix1, npix1 * 2, hipMemcpyDeviceToHost, h->stream_out));
+  HIPCHK(h, hipStreamSynchronize(h->stream_out));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
 int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t left_stride, const uint8_t* const* right,
                       size_t right_stride, int width, int height, int16_t* const* disp, size_t disp_stride) {
   if (!h || !left || !right || !disp) return SBM_ERR_NULL;
@@ -524,6 +587,9 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
   // transfer per row (measured 5.6 ms per 1242x375 pair against 0.2 ms packed).
   const bool in_dense = left_stride == (size_t)width && right_stride == (size_t)width;
   const bool out_dense = disp_stride == (size_t)width * 2;
+  static const int pipe_env = [] { const char* e = getenv("SBM_HOST_PIPELINE"); return e ? atoi(e) : 1; }();
+  if (in_dense && out_dense && n >= 16 && pipe_env && !h->profiling)
+    return compute_batch_pipelined(h, n, left, right, width, height, disp);
   if (!in_dense || !out_dense) {
     const size_t need = (size_t)n * npix1 * 4;
     if (need > h->pin_bytes) {
