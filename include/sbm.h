@@ -89,6 +89,11 @@ int sbm_params_validate(const sbm_params* p, int width, int height);
 int sbm_create(sbm_handle** out, const sbm_params* p, int device);
 void sbm_destroy(sbm_handle* h);
 
+/* Destroyed handles are parked (streams, events and up to 512 MB of device scratch each, at most 4) so that the
+ * reference's pattern -- a new matcher per frame, src/slam/src/core/main.cpp:201 -- does not pay ~2 ms of set-up per
+ * frame. sbm_trim() frees everything that is parked (e.g. before the process hands the GPU to someone else). */
+void sbm_trim(void);
+
 /* Replace the parameter block (the cv::StereoBM setters). Cheap; scratch is re-sized lazily. */
 int sbm_set_params(sbm_handle* h, const sbm_params* p);
 int sbm_get_params(const sbm_handle* h, sbm_params* p);

@@ -356,3 +356,24 @@ def test_randomised_parameter_sweep(torch_cuda, pkg, oracle):
             assert_stages_equal(eng, ref, kw)
         except AssertionError as e:
             raise AssertionError(f"iteration {it}: {h}x{w} {kw}: {e}")
+
+
+def test_matcher_recreated_every_frame(torch_cuda, pkg, oracle):
+    """The reference builds a new matcher per frame (main.cpp:201): destroyed handles are parked and re-armed, so changing
+    parameters and sizes between incarnations must give the same results as fresh handles, and trim() must free them."""
+    from u96_slam_amd import synth
+
+    cases = [(320, 96, 32, 9), (320, 96, 32, 9), (333, 77, 64, 15), (320, 96, 48, 21), (640, 200, 64, 9), (320, 96, 32, 9)]
+    for i, (W, H, nd, wsz) in enumerate(cases):
+        L, R = synth.make_pair(40 + i, W, H, nd)
+        bm = pkg.StereoBM.create(16, 9)
+        bm.setBlockSize(wsz); bm.setNumDisparities(nd); bm.setTextureThreshold(10); bm.setUniquenessRatio(10)
+        bm.setDisp12MaxDiff(1); bm.setSpeckleWindowSize(30); bm.setSpeckleRange(16)
+        got = bm.compute(L, R)
+        del bm
+        p = oracle.make_params(num_disparities=nd, block_size=wsz, texture_threshold=10, uniqueness_ratio=10,
+                               disp12_max_diff=1, speckle_window_size=30, speckle_range=16)
+        assert np.array_equal(got, oracle.compute(p, L, R)), f"incarnation {i}"
+        if i == 3:
+            pkg.trim()
+    pkg.trim()

@@ -11,7 +11,7 @@ There is no CPU fallback in this package: constructing a StereoBM without the bu
 GPU raises. The CPU oracle lives in /oracle and is only used by the tests and by bench.py's cpu_baseline leg.
 """
 from .stereobm import (StereoBM, StereoBMError, SbmParams, StereoModel, library_path, load_library, PREFILTER_XSOBEL,  # noqa: F401
-                       PREFILTER_NORMALIZED_RESPONSE, RectCam, make_rect_cam, PREFILTER_FLAVOUR_CV, PREFILTER_FLAVOUR_RTL)
+                       PREFILTER_NORMALIZED_RESPONSE, RectCam, make_rect_cam, PREFILTER_FLAVOUR_CV, PREFILTER_FLAVOUR_RTL, trim)
 
 __all__ = ["StereoBM", "StereoBMError", "SbmParams", "StereoModel", "library_path", "load_library", "PREFILTER_XSOBEL",
-           "PREFILTER_NORMALIZED_RESPONSE", "RectCam", "make_rect_cam", "PREFILTER_FLAVOUR_CV", "PREFILTER_FLAVOUR_RTL"]
+           "PREFILTER_NORMALIZED_RESPONSE", "RectCam", "make_rect_cam", "PREFILTER_FLAVOUR_CV", "PREFILTER_FLAVOUR_RTL", "trim"]

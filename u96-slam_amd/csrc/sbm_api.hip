@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 #include "sbm_common.h"
@@ -130,11 +131,53 @@ static void free_staging(sbm_handle* h) {
   h->st_l = h->st_r = nullptr; h->st_d = nullptr; h->st_n = h->st_W = h->st_H = 0;
 }
 
+// The reference re-creates its matcher for every frame (cv::StereoBM::create inside the loop, main.cpp:201). Streams,
+// ~400 events and the device scratch make a cold handle cost ~2 ms -- ten times the frame itself -- so destroyed handles
+// are parked (a few, with at most kPoolScratch bytes of scratch each) and sbm_create re-arms one for the same device.
+static std::mutex g_pool_mu;
+static constexpr int kPool = 4;
+static constexpr size_t kPoolScratch = (size_t)512 << 20;
+static sbm_handle* g_pool[kPool];
+static int g_pool_n = 0;
+
+static size_t scratch_bytes(const sbm_handle* h) {
+  const size_t npix = (size_t)h->cap_n * h->cap_W * h->cap_H, plane = (size_t)h->cap_n * h->cap_pitch * h->cap_H;
+  size_t b = 2 * plane + npix * 2;
+  if (h->cost) b += npix * 4;
+  if (h->labels) b += npix * 8;
+  b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
+  return b;
+}
+
+static void destroy_now(sbm_handle* h);
+
+void sbm_trim(void) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (int i = 0; i < g_pool_n; i++) destroy_now(g_pool[i]);
+  g_pool_n = 0;
+}
+
 int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
   if (!out || !p) return SBM_ERR_NULL;
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SBM_ERR_NO_DEVICE;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (int i = 0; i < g_pool_n; i++)
+      if (g_pool[i]->device == device) {
+        sbm_handle* h = g_pool[i];
+        g_pool[i] = g_pool[--g_pool_n];
+        h->p = *p;
+        h->last_hip = 0;
+        h->have_last = false;
+        h->profiling = 0;
+        h->calls = 0;
+        h->ms_prefilter = h->ms_sad = h->ms_border = h->ms_lr = h->ms_speckle = h->ms_total = 0.f;
+        *out = h;
+        return SBM_OK;
+      }
+  }
   sbm_handle* h = new (std::nothrow) sbm_handle();
   if (!h) return SBM_ERR_NOMEM;
   memset(h, 0, sizeof(*h));
@@ -164,6 +207,24 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
 
 void sbm_destroy(sbm_handle* h) {
   if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  hipStreamSynchronize(h->stream2);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool_n < kPool) {
+      if (scratch_bytes(h) > kPoolScratch) {
+        free_scratch(h);
+        free_staging(h);
+      }
+      g_pool[g_pool_n++] = h;
+      return;
+    }
+  }
+  destroy_now(h);
+}
+
+static void destroy_now(sbm_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   free_scratch(h);

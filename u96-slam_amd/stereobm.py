@@ -362,6 +362,11 @@ class StereoBM:
         return a
 
 
+def trim():
+    """Free the handles parked by destroyed matchers (see sbm_trim in include/sbm.h)."""
+    load_library().sbm_trim()
+
+
 def validate(params, width, height):
     """Status code of cv::StereoBM::compute's parameter checks (0 = ok)."""
     return load_library().sbm_params_validate(ctypes.byref(params), width, height)
