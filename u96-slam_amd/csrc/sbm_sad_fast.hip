@@ -425,6 +425,10 @@ template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, hipStream_t s) {
   if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, grid, s);
   if (a.nd == 48) return launch_t<32, 2, NTERM, PW>(a, grid, s);   // the masked single-wavefront variant needs 174 VGPRs
+  // one-pair calls: too few workgroups to fill the chip, so split the disparities over two wavefronts (half the serial work
+  // per row; SBM_FAST_SPLIT=0 disables)
+  static const int split_env = [] { const char* e = getenv("SBM_FAST_SPLIT"); return e ? atoi(e) : 1; }();
+  if (a.nd <= 64 && a.nd > 32 && grid.x < 1024 && split_env) return launch_t<32, 2, NTERM, PW>(a, grid, s);
   if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, grid, s);
   if constexpr (PW == 3) {
     if (a.nd <= 128 && mode == 1) return launch_t<128, 1, NTERM, PW>(a, grid, s);
