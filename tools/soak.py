@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Soak test on the GPU: many seeded random configurations (sizes, windows 5..29, disparity counts, every post-filter
+combination, batches) against the oracle, stage by stage; every configuration is also run twice for determinism.
+usage: python tools/soak.py [--iters 400] [--seed 1]   -> prints a JSON summary, exit code 1 on any mismatch"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import numpy as np
+    import _pkg
+
+    pkg = _pkg.load()
+    import sbm_oracle as oracle
+    from test_gpu_parity import assert_stages_equal, rand_pair, run_engine
+
+    rng = np.random.default_rng(args.seed)
+    bad = []
+    t0 = time.time()
+    for it in range(args.iters):
+        wsz = int(rng.choice([5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29]))
+        nd = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 192, 208, 256, 272]))
+        mind = int(rng.choice([0, 0, 0, -16, 5, -nd // 2, 17]))
+        n = int(rng.choice([1, 1, 2, 3, 5]))
+        h = int(rng.integers(wsz + 8, wsz + 90))
+        lo = max(nd + abs(mind), 0) + 2 * wsz + 8
+        w = int(rng.integers(lo, lo + 300))
+        kw = dict(num_disparities=nd, block_size=wsz, min_disparity=mind, prefilter_cap=int(rng.choice([31, 31, 15, 63, 1, 40])),
+                  texture_threshold=int(rng.choice([0, 10, 10, 200, 1000])), uniqueness_ratio=int(rng.choice([0, 5, 10, 15, 40, 90])),
+                  disp12_max_diff=int(rng.choice([-1, 0, 1, 1, 3])))
+        if rng.random() < 0.6:
+            kw.update(speckle_window_size=int(rng.choice([1, 10, 50, 200, 1000])), speckle_range=int(rng.choice([0, 4, 16, 32, 100])))
+        pairs = [rand_pair(rng, h, w, shift=int(rng.integers(0, 14)), noise=int(rng.integers(0, 8))) for _ in range(n)]
+        L = np.stack([p[0] for p in pairs]); R = np.stack([p[1] for p in pairs])
+        if rng.random() < 0.3:
+            L = (L // 64 * 64).astype(np.uint8); R = (R // 64 * 64).astype(np.uint8)
+        if n == 1 and rng.random() < 0.5:
+            L, R = L[0], R[0]
+        try:
+            eng, ref = run_engine(pkg, oracle, kw, L, R)
+            assert_stages_equal(eng, ref, kw)
+            eng2, _ = run_engine(pkg, oracle, kw, L, R, stages=False)
+            assert np.array_equal(eng2["disp"], eng["disp"]), "second run differs"
+        except AssertionError as e:
+            bad.append({"iteration": it, "shape": [n, h, w], "params": kw, "error": str(e)[:200]})
+    print(json.dumps({"iterations": args.iters, "seed": args.seed, "mismatches": len(bad), "seconds": round(time.time() - t0, 1),
+                      "first": bad[:3]}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
