@@ -35,6 +35,25 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container can see
+    256 CPUs and be limited to 16 CPUs' worth of time; threads beyond the quota only add throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = pathlib.Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]   # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            q = int(pathlib.Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())        # cgroup v1
+            per = int(pathlib.Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,8 +203,7 @@ def main():
         if not args.no_cpu_baseline:
             import sbm_oracle
 
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = max(1, min(cores, sbm_oracle.max_threads()))
+            cores = max(1, min(usable_cores(), sbm_oracle.max_threads()))
             p = sbm_oracle.make_params(nd, wsz, 31, 0, 10, 10, 50 if post else 0, 32 if post else 0, 1 if post else -1)
             t1 = time.perf_counter()
             sbm_oracle.compute_batch(p, Lh[:1], Rh[:1], threads=1)
