@@ -68,7 +68,12 @@ __device__ __forceinline__ u32 pk_add_sat(u32 a, u32 b) {
   u16x2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
   return __builtin_bit_cast(u32, r);
 }
-__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(a, min(b, c)); }
+// one v_min3_u32 (the compiler re-associates min(a, min(b, c)) chains and then only finds about half of them)
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) {
+  u32 r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NSLOT 16-byte slots, then exchange area
 
