@@ -198,6 +198,13 @@ def main():
                     "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
                     "stage_ms": {k: round(v, 4) for k, v in prof.items()}, **pmc_extra}
 
+        # the one stage of the path that IS HBM-bound: the prefilter, 1 B read + 1 B written per pixel and image
+        pf_ms = prof.get("prefilter", 0.0)
+        pf_bytes = 4.0 * W * H * B
+        roofline_pf = {"bound": "hbm", "kernel": "prefilter_kernel", "achieved": round(pf_bytes / (pf_ms * 1e-3) / 1e9, 2) if pf_ms > 0 else 0.0,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pf_bytes / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pf_ms > 0 else 0.0,
+                       "kernel_ms": round(pf_ms, 4), "algorithmic_bytes_per_launch": pf_bytes}
+
         # ---- CPU baseline (reported only) --------------------------------------------------------------------------
         cpu = None
         if not args.no_cpu_baseline:
@@ -231,7 +238,7 @@ def main():
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, " + ("disparity maps gathered on rank 0 each step" if (args.gather and world > 1) else "no data-path collective")},
             "ms_per_pair": round(elapsed / (B * args.steps) * 1e3, 5),
             "pairs_per_s": round(total_pairs / elapsed, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_prefilter": roofline_pf, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:
