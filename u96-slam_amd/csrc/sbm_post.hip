@@ -259,8 +259,9 @@ struct RowWalk {
   // masks of the chunk at column cb_ (lanes beyond the row hold newval = invalid)
   __device__ __forceinline__ void step(int v, int cb_, int lane, int newval, int maxdiff) {
     cb = cb_;
-    int pv = __shfl_up(v, 1, 64);
-    if (lane == 0) pv = prev_last;
+    // value of the left neighbour: full-rate DPP wave shift; lane 0 has no source lane and keeps `old` = prev_last
+    // (__shfl_up would be a ds_bpermute_b32 -- an LDS crossbar round trip inside the serial chain of the walk)
+    const int pv = __builtin_amdgcn_update_dpp(prev_last, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     valid = __ballot(v != newval);
     const unsigned long long closem = __ballot(abs(v - pv) <= maxdiff);
     const unsigned long long pvalid = (valid << 1) | (prev_valid ? 1ull : 0ull);
@@ -276,7 +277,7 @@ struct RowWalk {
     const bool v63 = (valid >> 63) & 1ull;
     carry = v63 ? (head ? cb + (63 - __clzll((long long)head)) : carry) : -1;
     prev_valid = v63;
-    prev_last = __shfl(v, 63, 64);
+    prev_last = __builtin_amdgcn_readlane(v, 63);
   }
   // bit position (0..63) of the head of the run that contains pixel 63 of this chunk, -1 if that run started earlier
   __device__ __forceinline__ int last_head_bit() const { return head ? 63 - __clzll((long long)head) : -1; }
