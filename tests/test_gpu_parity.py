@@ -377,3 +377,31 @@ def test_matcher_recreated_every_frame(torch_cuda, pkg, oracle):
         if i == 3:
             pkg.trim()
     pkg.trim()
+
+
+def test_two_handles_interleaved_without_sync(torch_cuda, pkg, oracle):
+    """Distinct handles own distinct streams and scratch: asynchronous launches on two of them, interleaved, must not
+    disturb each other (include/sbm.h: 'distinct handles may be used concurrently')."""
+    torch = torch_cuda
+    from u96_slam_amd import synth
+
+    cfgs = [(640, 200, 64, 9), (333, 120, 32, 15)]
+    hs, ins, outs, refs = [], [], [], []
+    for i, (W, H, nd, wsz) in enumerate(cfgs):
+        L, R = synth.make_batch(60 + 4 * i, 4, W, H, nd)
+        bm = pkg.StereoBM.create(nd, wsz)
+        bm.setTextureThreshold(10); bm.setUniquenessRatio(10); bm.setDisp12MaxDiff(1)
+        bm.setSpeckleWindowSize(30); bm.setSpeckleRange(16)
+        dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        hs.append(bm); ins.append((dL, dR)); outs.append(torch.empty((4, H, W), dtype=torch.int16, device="cuda"))
+        p = oracle.make_params(num_disparities=nd, block_size=wsz, texture_threshold=10, uniqueness_ratio=10,
+                               disp12_max_diff=1, speckle_window_size=30, speckle_range=16)
+        refs.append(oracle.compute_batch(p, L, R))
+    torch.cuda.synchronize()
+    for _ in range(10):
+        for bm, (dL, dR), o in zip(hs, ins, outs):
+            bm.compute_device(dL, dR, o, sync=False)
+    for bm in hs:
+        bm.synchronize()
+    for o, r in zip(outs, refs):
+        assert np.array_equal(o.cpu().numpy(), r)
