@@ -207,7 +207,7 @@ def main():
 
         # ---- CPU baseline (reported only) --------------------------------------------------------------------------
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             import sbm_oracle
 
             cores = max(1, min(usable_cores(), sbm_oracle.max_threads()))
