@@ -41,7 +41,7 @@ enum {
   SBM_OK = 0,
   SBM_ERR_NULL = -1,             /* null handle / pointer argument                                   */
   SBM_ERR_SIZE = -2,             /* width/height <= 0, stride < width, left/right size mismatch       */
-  SBM_ERR_PREFILTER_TYPE = -3,   /* preFilterType not XSOBEL (NORMALIZED_RESPONSE: not built yet)     */
+  SBM_ERR_PREFILTER_TYPE = -3,   /* preFilterType must be NORMALIZED_RESPONSE or XSOBEL               */
   SBM_ERR_PREFILTER_SIZE = -4,   /* preFilterSize must be odd and within 5..255                       */
   SBM_ERR_PREFILTER_CAP = -5,    /* preFilterCap must be within 1..63                                 */
   SBM_ERR_BLOCK_SIZE = -6,       /* blockSize must be odd, within 5..255 and < min(width,height)      */

@@ -439,6 +439,50 @@ void sbmo_filter_speckles(int16_t* img, size_t stride, int width, int height, in
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Prefilter, PREFILTER_NORMALIZED_RESPONSE.  Follows prefilterNorm() in OpenCV calib3d stereobm.cpp
+ * (not used by the reference, restated for the completeness of the cv::StereoBM surface):
+ *   box(x,y)  = sum of src over the winsize x winsize window centred on (x,y), rows and columns
+ *               replicated at the image border (OpenCV keeps the column sums in ushort; winsize*255
+ *               fits, so nothing wraps)
+ *   g0 = winsize*winsize/8, ss = (1024 + g0)/(2*g0), sg = g0*ss         (integer divisions)
+ *   centre    = 4*src(x,y) + src(x-1,y) + src(x+1,y) + src(x,y-1) + src(x,y+1), rows replicated;
+ *               in columns 0 and W-1 the missing horizontal neighbour is replaced by the centre
+ *               pixel (5*src + the one existing neighbour + up + down)
+ *   val       = (centre*sg - box*ss) >> 10      (arithmetic shift)
+ *   dst       = val < -cap ? 0 : val > cap ? 2*cap : val + cap
+ * ------------------------------------------------------------------------------------------------ */
+void sbmo_prefilter_norm(const uint8_t* src, size_t sstride, uint8_t* dst, size_t dstride, int width, int height,
+                         int winsize, int cap) {
+  const int wsz2 = winsize / 2;
+  const int g0 = winsize * winsize / 8;
+  const int ss = g0 > 0 ? (1024 + g0) / (g0 * 2) : 0;
+  const int sg = g0 * ss;
+  int* vsum = (int*)malloc(sizeof(int) * (size_t)width);
+  for (int y = 0; y < height; y++) {
+    for (int x = 0; x < width; x++) {
+      int v = 0;
+      for (int dy = -wsz2; dy <= wsz2; dy++) v += src[(size_t)iclamp(y + dy, 0, height - 1) * sstride + x];
+      vsum[x] = v;
+    }
+    const uint8_t* prev = src + (size_t)imax(y - 1, 0) * sstride;
+    const uint8_t* curr = src + (size_t)y * sstride;
+    const uint8_t* next = src + (size_t)imin(y + 1, height - 1) * sstride;
+    for (int x = 0; x < width; x++) {
+      int box = 0;
+      for (int dx = -wsz2; dx <= wsz2; dx++) box += vsum[iclamp(x + dx, 0, width - 1)];
+      int centre;
+      if (width == 1) centre = curr[x] * 6 + prev[x] + next[x];   /* degenerate: OpenCV's first-column formula reads curr[1] */
+      else if (x == 0) centre = curr[x] * 5 + curr[x + 1] + prev[x] + next[x];
+      else if (x == width - 1) centre = curr[x] * 5 + curr[x - 1] + prev[x] + next[x];
+      else centre = curr[x] * 4 + curr[x - 1] + curr[x + 1] + prev[x] + next[x];
+      const int val = (centre * sg - box * ss) >> 10;
+      dst[(size_t)y * dstride + x] = (uint8_t)(val < -cap ? 0 : (val > cap ? 2 * cap : val + cap));
+    }
+  }
+  free(vsum);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Parameter checks of cv::StereoBM::compute (stereobm.cpp), one status code per CV_Error.
  * (The product library implements the same table in its own source; the two are compared by tests.)
  * ------------------------------------------------------------------------------------------------ */
@@ -454,7 +498,6 @@ static int oracle_validate(const sbm_params* p, int width, int height) {
   if (p->num_disparities <= 0 || p->num_disparities % 16 != 0) return SBM_ERR_NUM_DISPARITIES;
   if (p->texture_threshold < 0) return SBM_ERR_TEXTURE;
   if (p->uniqueness_ratio < 0) return SBM_ERR_UNIQUENESS;
-  if (p->prefilter_type == SBM_PREFILTER_NORMALIZED_RESPONSE) return SBM_ERR_PREFILTER_TYPE; /* not restated */
   return SBM_OK;
 }
 
@@ -498,8 +541,13 @@ int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const
     free(pl); free(pr); free(cost);
     return SBM_ERR_NOMEM;
   }
-  sbmo_prefilter_xsobel(left, lstride, pl, (size_t)width, width, height, p->prefilter_cap);
-  sbmo_prefilter_xsobel(right, rstride, pr, (size_t)width, width, height, p->prefilter_cap);
+  if (p->prefilter_type == SBM_PREFILTER_XSOBEL) {
+    sbmo_prefilter_xsobel(left, lstride, pl, (size_t)width, width, height, p->prefilter_cap);
+    sbmo_prefilter_xsobel(right, rstride, pr, (size_t)width, width, height, p->prefilter_cap);
+  } else {
+    sbmo_prefilter_norm(left, lstride, pl, (size_t)width, width, height, p->prefilter_size, p->prefilter_cap);
+    sbmo_prefilter_norm(right, rstride, pr, (size_t)width, width, height, p->prefilter_size, p->prefilter_cap);
+  }
   if (pf_l_out) memcpy(pf_l_out, pl, npix);
   if (pf_r_out) memcpy(pf_r_out, pr, npix);
 

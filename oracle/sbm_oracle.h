@@ -37,6 +37,10 @@ extern "C" {
 void sbmo_prefilter_xsobel(const uint8_t* src, size_t sstride, uint8_t* dst, size_t dstride, int width, int height,
                            int cap);
 
+/* OpenCV prefilterNorm (PREFILTER_NORMALIZED_RESPONSE). Not used by the reference; parity unpinned. */
+void sbmo_prefilter_norm(const uint8_t* src, size_t sstride, uint8_t* dst, size_t dstride, int width, int height,
+                         int winsize, int cap);
+
 /* FPGA flavour: src/dvp/rtl/xsbl2.v (limit() 185-198, horizontal diff 684-698, line buffers 787-857,
  * edge substitution 869-872, row index hcnt-1 1020-1025). Rows 0 and H-1 are left at `fill` (the
  * testbench zero-fills them, src/dvp/sim/sim_dvp.v:524-542). */

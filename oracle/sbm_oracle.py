@@ -158,6 +158,18 @@ def prefilter_xsobel(img, cap):
     return out
 
 
+def prefilter_norm(img, winsize, cap):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    L = lib()
+    L.sbmo_prefilter_norm.argtypes = [ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint8),
+                                      ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.sbmo_prefilter_norm.restype = None
+    L.sbmo_prefilter_norm(_p(img, ctypes.c_uint8), w, _p(out, ctypes.c_uint8), w, w, h, winsize, cap)
+    return out
+
+
 def prefilter_xsobel_fpga(img, fill=0):
     img = _u8(img)
     out = np.empty_like(img)

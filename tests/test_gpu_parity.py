@@ -255,7 +255,7 @@ def test_degenerate_and_error_behaviour(torch_cuda, pkg, oracle):
     assert (d[4:-4, 19:-4] == 15 * 16).all()
     for setter, val, code in (("setNumDisparities", 20, -7), ("setBlockSize", 4, -6), ("setBlockSize", 41, -6),
                               ("setPreFilterCap", 64, -5), ("setTextureThreshold", -1, -8),
-                              ("setUniquenessRatio", -1, -9), ("setPreFilterType", 0, -3)):
+                              ("setUniquenessRatio", -1, -9), ("setPreFilterType", 2, -3), ("setPreFilterSize", 8, -4)):
         bm2 = pkg.StereoBM.create(16, 9)
         getattr(bm2, setter)(val)
         with pytest.raises(pkg.StereoBMError) as e:
@@ -264,7 +264,8 @@ def test_degenerate_and_error_behaviour(torch_cuda, pkg, oracle):
         assert oracle.compute_status(oracle.make_params(**{"num_disparities": 16, "block_size": 9,
                                                            {"setNumDisparities": "num_disparities", "setBlockSize": "block_size",
                                                             "setPreFilterCap": "prefilter_cap", "setTextureThreshold": "texture_threshold",
-                                                            "setUniquenessRatio": "uniqueness_ratio", "setPreFilterType": "prefilter_type"}[setter]: val}),
+                                                            "setUniquenessRatio": "uniqueness_ratio", "setPreFilterType": "prefilter_type",
+                                                            "setPreFilterSize": "prefilter_size"}[setter]: val}),
                                      64, 40) == code
     with pytest.raises(pkg.StereoBMError):
         bm.compute(flat, flat[:, :60])
@@ -405,3 +406,35 @@ def test_two_handles_interleaved_without_sync(torch_cuda, pkg, oracle):
         bm.synchronize()
     for o, r in zip(outs, refs):
         assert np.array_equal(o.cpu().numpy(), r)
+
+
+@pytest.mark.parametrize("h,w,kw", [
+    (60, 150, dict(num_disparities=32, block_size=9, prefilter_type=0, prefilter_size=9, prefilter_cap=31, texture_threshold=10,
+                   uniqueness_ratio=10, disp12_max_diff=1)),
+    (47, 131, dict(num_disparities=16, block_size=15, prefilter_type=0, prefilter_size=5, prefilter_cap=63, texture_threshold=0,
+                   uniqueness_ratio=5, disp12_max_diff=1, speckle_window_size=20, speckle_range=16)),
+    (80, 260, dict(num_disparities=64, block_size=21, prefilter_type=0, prefilter_size=21, prefilter_cap=15, texture_threshold=10,
+                   uniqueness_ratio=10, disp12_max_diff=1)),
+    (33, 90, dict(num_disparities=16, block_size=7, prefilter_type=0, prefilter_size=41, prefilter_cap=31)),
+    (40, 300, dict(num_disparities=128, block_size=11, prefilter_type=0, prefilter_size=255, prefilter_cap=31, disp12_max_diff=0)),
+])
+def test_normalized_response_prefilter(torch_cuda, pkg, oracle, h, w, kw):
+    """PREFILTER_NORMALIZED_RESPONSE (cv prefilterNorm): every stage bit-exact against the oracle, batches included."""
+    rng = np.random.default_rng(h * 1000 + w)
+    pairs = [rand_pair(rng, h, w, shift=4, noise=3) for _ in range(3)]
+    L = np.stack([p[0] for p in pairs]); R = np.stack([p[1] for p in pairs])
+    bm = pkg.StereoBM.create(kw["num_disparities"], kw["block_size"])
+    bm.setPreFilterType(pkg.PREFILTER_NORMALIZED_RESPONSE)
+    bm.setPreFilterSize(kw["prefilter_size"])
+    setters = dict(prefilter_cap=bm.setPreFilterCap, texture_threshold=bm.setTextureThreshold, uniqueness_ratio=bm.setUniquenessRatio,
+                   speckle_window_size=bm.setSpeckleWindowSize, speckle_range=bm.setSpeckleRange, disp12_max_diff=bm.setDisp12MaxDiff)
+    for k, v in kw.items():
+        if k in setters:
+            setters[k](v)
+    got = bm.compute(L, R)
+    pf_l, pf_r = bm.debug_fetch(0, 3, h, w), bm.debug_fetch(1, 3, h, w)
+    p = oracle.make_params(**kw)
+    for i in range(3):
+        assert np.array_equal(pf_l[i], oracle.prefilter_norm(L[i], kw["prefilter_size"], kw["prefilter_cap"]))
+        assert np.array_equal(pf_r[i], oracle.prefilter_norm(R[i], kw["prefilter_size"], kw["prefilter_cap"]))
+        assert np.array_equal(got[i], oracle.compute(p, L[i], R[i]))

@@ -238,3 +238,54 @@ def test_map_consumers_match_numpy_restatement(oracle):
         kp = np.array([[10.7, 7.2], [79.9, 49.9], [-1, 3], [5, 50]], np.float32)
         k3 = oracle.keypoints3d(d, kp, m, 0.0, 0.0)
         assert np.isnan(k3[2]).all() and np.isnan(k3[3]).all()
+
+
+def _prefilter_norm_incremental(src, winsize, ftzero):
+    """prefilterNorm as OpenCV writes it (incremental column sums in ushort, padded vsum, sliding row sum, lookup table):
+    an independent, literal restatement to check the oracle's closed form against."""
+    h, w = src.shape
+    wsz2 = winsize // 2
+    scale_g = winsize * winsize // 8
+    scale_s = (1024 + scale_g) // (scale_g * 2)
+    scale_g *= scale_s
+    OFS = 256 * 5
+    TABSZ = OFS * 2 + 256
+    tab = [0 if x - OFS < -ftzero else (ftzero * 2 if x - OFS > ftzero else x - OFS + ftzero) for x in range(TABSZ)]
+    s = src.astype(np.int64)
+    pad = wsz2 + 1
+    vsum = np.zeros(w + 2 * pad, np.int64)      # vsum[pad + x]
+    vsum[pad:pad + w] = (s[0] * (wsz2 + 2)) & 0xFFFF
+    for y in range(1, wsz2):
+        vsum[pad:pad + w] = (vsum[pad:pad + w] + s[min(y, h - 1)]) & 0xFFFF
+    dst = np.zeros((h, w), np.uint8)
+    for y in range(h):
+        top = s[max(y - wsz2 - 1, 0)]
+        bottom = s[min(y + wsz2, h - 1)]
+        prev, curr, nxt = s[max(y - 1, 0)], s[y], s[min(y + 1, h - 1)]
+        vsum[pad:pad + w] = (vsum[pad:pad + w] + bottom - top) & 0xFFFF
+        for x in range(wsz2 + 1):
+            vsum[pad - x - 1] = vsum[pad]
+            vsum[pad + w + x] = vsum[pad + w - 1]
+        tot = int(vsum[pad]) * (wsz2 + 1) + int(vsum[pad + 1:pad + wsz2 + 1].sum())
+        val = ((int(curr[0]) * 5 + int(curr[1]) + int(prev[0]) + int(nxt[0])) * scale_g - tot * scale_s) >> 10
+        dst[y, 0] = tab[val + OFS]
+        for x in range(1, w - 1):
+            tot += int(vsum[pad + x + wsz2]) - int(vsum[pad + x - wsz2 - 1])
+            val = ((int(curr[x]) * 4 + int(curr[x - 1]) + int(curr[x + 1]) + int(prev[x]) + int(nxt[x])) * scale_g - tot * scale_s) >> 10
+            dst[y, x] = tab[val + OFS]
+        x = w - 1
+        tot += int(vsum[pad + x + wsz2]) - int(vsum[pad + x - wsz2 - 1])
+        val = ((int(curr[x]) * 5 + int(curr[x - 1]) + int(prev[x]) + int(nxt[x])) * scale_g - tot * scale_s) >> 10
+        dst[y, x] = tab[val + OFS]
+    return dst
+
+
+@pytest.mark.parametrize("h,w,win,cap", [(24, 31, 9, 31), (17, 40, 5, 63), (30, 22, 15, 10), (12, 45, 21, 31)])
+def test_prefilter_norm_closed_form_equals_incremental_form(oracle, h, w, win, cap):
+    """Both restatements come from the same recollection of OpenCV (parity unpinned); this pins them to each other: the
+    oracle's windowed definition vs the running-sum code with its ushort column sums, padding and initial row weights.
+    (The incremental form needs the image to be taller than the half window, as OpenCV's initialisation loop assumes.)"""
+    rng = np.random.default_rng(h * w + win)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    assert h > win // 2
+    assert np.array_equal(oracle.prefilter_norm(img, win, cap), _prefilter_norm_incremental(img, win, cap))

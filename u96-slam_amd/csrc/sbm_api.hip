@@ -28,6 +28,7 @@ struct sbm_handle {
   uint8_t *pf_l, *pf_r;
   int16_t* disp_pre;
   int32_t *cost, *labels, *counts;
+  uint16_t* vsum;      // column sums of PREFILTER_NORMALIZED_RESPONSE (2 * cap_n * W * H), allocated on first use
   // staging for the host-buffer entry points
   int st_n, st_W, st_H;
   uint8_t *st_l, *st_r;
@@ -91,7 +92,6 @@ int sbm_params_validate(const sbm_params* p, int width, int height) {
   if (p->num_disparities <= 0 || p->num_disparities % 16 != 0) return SBM_ERR_NUM_DISPARITIES;
   if (p->texture_threshold < 0) return SBM_ERR_TEXTURE;
   if (p->uniqueness_ratio < 0) return SBM_ERR_UNIQUENESS;
-  if (p->prefilter_type == SBM_PREFILTER_NORMALIZED_RESPONSE) return SBM_ERR_PREFILTER_TYPE;  // not built yet
   return SBM_OK;
 }
 
@@ -100,7 +100,7 @@ const char* sbm_strerror(int code) {
     case SBM_OK: return "ok";
     case SBM_ERR_NULL: return "null argument";
     case SBM_ERR_SIZE: return "bad image size or stride (all the images must have the same size)";
-    case SBM_ERR_PREFILTER_TYPE: return "preFilterType must be PREFILTER_XSOBEL (NORMALIZED_RESPONSE is not built)";
+    case SBM_ERR_PREFILTER_TYPE: return "preFilterType must be PREFILTER_NORMALIZED_RESPONSE or PREFILTER_XSOBEL";
     case SBM_ERR_PREFILTER_SIZE: return "preFilterSize must be odd and be within 5..255";
     case SBM_ERR_PREFILTER_CAP: return "preFilterCap must be within 1..63";
     case SBM_ERR_BLOCK_SIZE: return "SADWindowSize must be odd, be within 5..255 and be not larger than image width or height";
@@ -120,6 +120,8 @@ int sbm_version(void) { return SBM_VERSION_MAJOR * 1000 + SBM_VERSION_MINOR; }
 
 static void free_scratch(sbm_handle* h) {
   hipFree(h->pf_l); hipFree(h->pf_r); hipFree(h->disp_pre); hipFree(h->cost); hipFree(h->labels); hipFree(h->counts);
+  hipFree(h->vsum);
+  h->vsum = nullptr;
   h->pf_l = h->pf_r = nullptr; h->disp_pre = nullptr; h->cost = h->labels = h->counts = nullptr;
   h->cap_n = h->cap_W = h->cap_H = h->cap_pitch = 0;
 }
@@ -382,7 +384,13 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
 
   mark(h, 0);
   if (any_rows) {
-    HIPCHK(h, launch_prefilter((const uint8_t*)d_left, (const uint8_t*)d_right, h->pf_l, h->pf_r, g, h->stream));
+    if (p.prefilter_type == SBM_PREFILTER_XSOBEL) {
+      HIPCHK(h, launch_prefilter((const uint8_t*)d_left, (const uint8_t*)d_right, h->pf_l, h->pf_r, g, h->stream));
+    } else {
+      if (!h->vsum) HIPCHK(h, hipMalloc((void**)&h->vsum, (size_t)2 * h->cap_n * width * height * sizeof(uint16_t)));
+      HIPCHK(h, launch_prefilter_norm((const uint8_t*)d_left, (const uint8_t*)d_right, h->pf_l, h->pf_r, h->vsum, g,
+                                      p.prefilter_size, h->stream));
+    }
   }
   mark(h, 1);
   if (any_rows) {

@@ -32,6 +32,10 @@ constexpr int kPfBias = 1;
 hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
                             const Geom& g, hipStream_t s);
 
+// PREFILTER_NORMALIZED_RESPONSE (cv prefilterNorm); vsum = 2*n*W*H uint16 scratch (column sums).
+hipError_t launch_prefilter_norm(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r, uint16_t* vsum,
+                                 const Geom& g, int winsize, hipStream_t s);
+
 // Generic SAD/WTA for output columns x in [xa,xb) (x relative to lofs) and rows [row0,row1): any block size,
 // any disparity count, clamped border windows. Used for the border columns and as the fallback path.
 hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,

@@ -189,6 +189,71 @@ hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// PREFILTER_NORMALIZED_RESPONSE (cv prefilterNorm; SURVEY.md A.2 -- not used by the reference, built so that the whole
+// cv::StereoBM parameter surface runs on the device).  Two passes over each image:
+//   1. column sums of the winsize rows around y (rows replicated at the border): one thread per column slides down a
+//      block of rows (coalesced across columns), uint16 plane in scratch;
+//   2. per pixel: horizontal sum of winsize column sums (columns replicated), centre-weighted term, clip to [0, 2 cap],
+//      written with the +1 bias into the padded plane like the x-Sobel output.
+// Both are small next to the SAD kernel at the default winsize 9 (O(winsize) loads per pixel in pass 2).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PFN_ROWS = 32;
+
+// grid: (ceil(W/256), ceil(H/PFN_ROWS), 2n)
+__global__ void __launch_bounds__(256) pf_norm_vsum_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                           uint16_t* __restrict__ vs, int W, int H, int wsz2) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int img = blockIdx.z >> 1;
+  const uint8_t* src = ((blockIdx.z & 1) ? right : left) + (size_t)img * W * H + x;
+  uint16_t* out = vs + (size_t)blockIdx.z * W * H + x;
+  const int y0 = blockIdx.y * PFN_ROWS, y1 = min(y0 + PFN_ROWS, H);
+  int sum = 0;
+  for (int dy = -wsz2; dy <= wsz2; dy++) sum += src[(size_t)min(max(y0 + dy, 0), H - 1) * W];
+  for (int y = y0; y < y1; y++) {
+    out[(size_t)y * W] = (uint16_t)sum;
+    sum += (int)src[(size_t)min(y + 1 + wsz2, H - 1) * W] - (int)src[(size_t)max(y - wsz2, 0) * W];
+  }
+}
+
+// grid: (ceil(W/256), H, 2n)
+__global__ void __launch_bounds__(256) pf_norm_resp_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                           const uint16_t* __restrict__ vs, uint8_t* __restrict__ pf_l,
+                                                           uint8_t* __restrict__ pf_r, int W, int H, int pitch, int padl,
+                                                           int plane, int wsz2, int sg, int ss, int cap) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int img = blockIdx.z >> 1;
+  const uint8_t* src = ((blockIdx.z & 1) ? right : left) + (size_t)img * W * H;
+  const uint16_t* v = vs + ((size_t)blockIdx.z * H + y) * W;
+  int box = 0;
+  for (int dx = -wsz2; dx <= wsz2; dx++) box += v[min(max(x + dx, 0), W - 1)];
+  const uint8_t* prev = src + (size_t)max(y - 1, 0) * W;
+  const uint8_t* curr = src + (size_t)y * W;
+  const uint8_t* next = src + (size_t)min(y + 1, H - 1) * W;
+  const int c = curr[x], lft = x > 0 ? curr[x - 1] : c, rgt = x < W - 1 ? curr[x + 1] : c;   // missing neighbour = centre
+  const int centre = 4 * c + lft + rgt + prev[x] + next[x];
+  const int val = (centre * sg - box * ss) >> 10;
+  const int o = val < -cap ? 0 : (val > cap ? 2 * cap : val + cap);
+  uint8_t* dst = ((blockIdx.z & 1) ? pf_r : pf_l) + (size_t)img * plane + (size_t)y * pitch + padl;
+  dst[x] = (uint8_t)(o + kPfBias);
+}
+
+hipError_t launch_prefilter_norm(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r, uint16_t* vsum,
+                                 const Geom& g, int winsize, hipStream_t s) {
+  const int wsz2 = winsize / 2;
+  const int g0 = winsize * winsize / 8;
+  const int ss = g0 > 0 ? (1024 + g0) / (g0 * 2) : 0;
+  const int sg = g0 * ss;
+  const unsigned gx = (unsigned)((g.W + 255) / 256);
+  hipLaunchKernelGGL(pf_norm_vsum_kernel, dim3(gx, (g.H + PFN_ROWS - 1) / PFN_ROWS, 2 * g.n), dim3(256), 0, s, d_left, d_right,
+                     vsum, g.W, g.H, wsz2);
+  hipLaunchKernelGGL(pf_norm_resp_kernel, dim3(gx, g.H, 2 * g.n), dim3(256), 0, s, d_left, d_right, vsum, pf_l, pf_r, g.W, g.H,
+                     g.pitch, g.padl, g.plane, wsz2, sg, ss, g.cap);
+  return hipGetLastError();
+}
+
 // Stand-alone prefilter of n dense images into n dense planes (no padding, no bias), either flavour.
 hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, int W, int H, int rtl, int cap,
                                   hipStream_t s) {
