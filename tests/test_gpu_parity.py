@@ -23,7 +23,8 @@ def run_engine(pkg, oracle, params_kw, L, R, stages=True):
     setters = dict(prefilter_cap=bm.setPreFilterCap, min_disparity=bm.setMinDisparity,
                    texture_threshold=bm.setTextureThreshold, uniqueness_ratio=bm.setUniquenessRatio,
                    speckle_window_size=bm.setSpeckleWindowSize, speckle_range=bm.setSpeckleRange,
-                   disp12_max_diff=bm.setDisp12MaxDiff, roi1=bm.setROI1, roi2=bm.setROI2)
+                   disp12_max_diff=bm.setDisp12MaxDiff, roi1=bm.setROI1, roi2=bm.setROI2,
+                   prefilter_type=bm.setPreFilterType, prefilter_size=bm.setPreFilterSize)
     for k, v in params_kw.items():
         if k in setters:
             setters[k](v)

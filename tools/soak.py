@@ -40,6 +40,8 @@ def main():
         kw = dict(num_disparities=nd, block_size=wsz, min_disparity=mind, prefilter_cap=int(rng.choice([31, 31, 15, 63, 1, 40])),
                   texture_threshold=int(rng.choice([0, 10, 10, 200, 1000])), uniqueness_ratio=int(rng.choice([0, 5, 10, 15, 40, 90])),
                   disp12_max_diff=int(rng.choice([-1, 0, 1, 1, 3])))
+        if rng.random() < 0.15:
+            kw.update(prefilter_type=0, prefilter_size=int(rng.choice([5, 9, 9, 15, 31, 63])))
         if rng.random() < 0.6:
             kw.update(speckle_window_size=int(rng.choice([1, 10, 50, 200, 1000])), speckle_range=int(rng.choice([0, 4, 16, 32, 100])))
         pairs = [rand_pair(rng, h, w, shift=int(rng.integers(0, 14)), noise=int(rng.integers(0, 8))) for _ in range(n)]
