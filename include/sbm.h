@@ -149,6 +149,10 @@ typedef struct sbm_stereo_model {
   int32_t has_local;                    /* 0 = localTransform().isNull()                                            */
 } sbm_stereo_model;
 
+/* The CV_32F form of the result (cv::StereoBM::compute into a CV_32F destination: disp16.convertTo(dst, CV_32F, 1./16)):
+ * out = disp / 16 as float, exact; FILTERED pixels become (minDisparity - 1). n*height*width floats. */
+int sbm_disparity_to_float_device(sbm_handle* h, int n, const void* d_disp, int width, int height, void* d_out, int sync);
+
 /* out[p][r][c] = disp[p][r*scale][c*scale]; out planes are (height/scale) x (width/scale), densely packed. */
 int sbm_decimate_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale, void* d_out, int sync);
 

@@ -82,17 +82,22 @@ class StereoBM {
   cv::Rect getROI1() const { return cv::Rect(p_.roi1[0], p_.roi1[1], p_.roi1[2], p_.roi1[3]); }
   cv::Rect getROI2() const { return cv::Rect(p_.roi2[0], p_.roi2[1], p_.roi2[2], p_.roi2[3]); }
 
-  // cv::StereoMatcher::compute(InputArray left, InputArray right, OutputArray disparity), CV_16SC1 result.
+  // cv::StereoMatcher::compute(InputArray left, InputArray right, OutputArray disparity): CV_16SC1, or CV_32FC1 if fixed.
   void compute(cv::InputArray leftarr, cv::InputArray rightarr, cv::OutputArray disparr) {
     if (leftarr.size() != rightarr.size()) CV_Error(cv::Error::StsUnmatchedSizes, "All the images must have the same size");
     if (leftarr.type() != CV_8UC1 || rightarr.type() != CV_8UC1)
       CV_Error(cv::Error::StsUnsupportedFormat, "Both input images must have CV_8UC1");
     cv::Mat left = leftarr.getMat(), right = rightarr.getMat();
-    disparr.create(left.size(), CV_16SC1);
-    cv::Mat disp = disparr.getMat();
+    // like cv::StereoBM: a destination with a fixed CV_32F type receives disparity / 16 as float, anything else CV_16SC1
+    const bool want_f32 = disparr.fixedType() && disparr.type() == CV_32FC1;
+    cv::Mat disp16;
+    if (want_f32) disp16.create(left.size(), CV_16SC1);
+    else disparr.create(left.size(), CV_16SC1);
+    cv::Mat disp = want_f32 ? disp16 : disparr.getMat();
     int st = sbm_compute(h_, left.ptr<uint8_t>(), left.step, right.ptr<uint8_t>(), right.step, left.cols, left.rows,
                          disp.ptr<int16_t>(), disp.step);
     if (st != SBM_OK) CV_Error(st <= SBM_ERR_NO_DEVICE ? cv::Error::StsError : cv::Error::StsOutOfRange, message(st));
+    if (want_f32) disp16.convertTo(disparr, CV_32F, 1. / 16);
   }
 #endif
 

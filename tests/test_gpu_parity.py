@@ -297,6 +297,17 @@ def _same_floats(a, b):
     return np.array_equal(na, nb) and np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32))
 
 
+def test_float_disparity_is_exact_sixteenth(torch_cuda, pkg):
+    """CV_32F output = int16 / 16 exactly (cv convertTo(CV_32F, 1./16)); odd element counts take the scalar tail."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4)
+    for shape in ((3, 37, 53), (61, 35), (2, 8, 16)):
+        d = rng.integers(-32768, 32768, shape).astype(np.int16)
+        bm = pkg.StereoBM.create(16, 9)
+        got = bm.to_float(torch.from_numpy(d).cuda()).cpu().numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, (d.astype(np.float64) / 16.0).astype(np.float32))
+
+
 def test_map_consumers_bit_exact(torch_cuda, pkg, oracle):
     """decimation (SensorData.cpp:50-58), reprojection (Stereo.cpp:157-199, main.cpp:522-553) and
     keypoint depth (Stereo.cpp:53-117) on the device vs the restatement of the reference's own C++ expressions.

@@ -480,6 +480,16 @@ int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int
   return SBM_OK;
 }
 
+int sbm_disparity_to_float_device(sbm_handle* h, int n, const void* d_disp, int width, int height, void* d_out, int sync) {
+  if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  if (width <= 0 || height <= 0) return SBM_ERR_SIZE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_disp_to_float((const int16_t*)d_disp, (float*)d_out, (size_t)n * width * height, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
 int sbm_decimate_device(sbm_handle* h, int n, const void* d_disp, int width, int height, int scale, void* d_out, int sync) {
   if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;

@@ -68,6 +68,7 @@ hipError_t launch_rect_remap(const uint8_t* d_src, const int16_t* d_map, uint8_t
                              hipStream_t s);
 
 // Consumers of the map (sbm_consume.hip): decimation, reprojection, keypoint depth.
+hipError_t launch_disp_to_float(const int16_t* disp, float* out, size_t count, hipStream_t s);
 hipError_t launch_decimate(const int16_t* disp, int16_t* out, int n, int W, int H, int scale, hipStream_t s);
 hipError_t launch_reproject(const int16_t* disp, float* xyz, int n, int W, int H, int scale, const sbm_stereo_model& m,
                             int apply_local, hipStream_t s);

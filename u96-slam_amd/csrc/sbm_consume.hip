@@ -101,6 +101,27 @@ __global__ void __launch_bounds__(256) keypoints3d_kernel(const int16_t* __restr
   xyz[3 * i + 2] = pt.z;
 }
 
+// cv::StereoBM::compute into a CV_32F destination: disp16.convertTo(dst, CV_32F, 1. / 16) -- exact in float
+__global__ void __launch_bounds__(256) disp_to_float_kernel(const int16_t* __restrict__ disp, float* __restrict__ out, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    short v[4];
+    __builtin_memcpy(v, disp + i, 8);
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = (float)((double)v[k] * (1.0 / 16.0));
+    __builtin_memcpy(out + i, f, 16);
+  } else {
+    for (size_t k = i; k < n; k++) out[k] = (float)((double)disp[k] * (1.0 / 16.0));
+  }
+}
+
+hipError_t launch_disp_to_float(const int16_t* disp, float* out, size_t count, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(disp_to_float_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, s, disp, out, count);
+  return hipGetLastError();
+}
+
 hipError_t launch_decimate(const int16_t* disp, int16_t* out, int n, int W, int H, int scale, hipStream_t s) {
   const int Wd = W / scale, Hd = H / scale;
   if (Wd <= 0 || Hd <= 0) return hipSuccess;

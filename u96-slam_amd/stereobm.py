@@ -108,6 +108,7 @@ def load_library():
     L.sbm_set_profiling.argtypes = [vp, ci]
     L.sbm_get_profile.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
     mp = ctypes.POINTER(StereoModel)
+    L.sbm_disparity_to_float_device.argtypes = [vp, ci, vp, ci, ci, vp, ci]
     L.sbm_decimate_device.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci]
     L.sbm_reproject_device.argtypes = [vp, ci, vp, ci, ci, ci, mp, ci, vp, ci]
     L.sbm_keypoints3d_device.argtypes = [vp, vp, ci, ci, vp, ci, mp, ctypes.c_float, ctypes.c_float, vp, ci]
@@ -261,6 +262,18 @@ class StereoBM:
         _check(self._L.sbm_compute_device(self._h, n, d_left, d_right, w, h, d_disp, 1 if sync else 0), self._h)
 
     # ---- consumers of the map (SensorData.cpp:50-58, Stereo.cpp:53-117,157-199, main.cpp:522-553) ----------------
+    def to_float(self, disp):
+        """CV_32F form of a torch CUDA int16 disparity tensor: disp / 16 as float32 (cv convertTo(CV_32F, 1/16))."""
+        import torch
+
+        disp = disp.contiguous()
+        h, w = disp.shape[-2], disp.shape[-1]
+        n = 1 if disp.dim() == 2 else disp.shape[0]
+        out = torch.empty(disp.shape, dtype=torch.float32, device=disp.device)
+        torch.cuda.current_stream(disp.device).synchronize()
+        _check(self._L.sbm_disparity_to_float_device(self._h, n, disp.data_ptr(), w, h, out.data_ptr(), 1), self._h)
+        return out
+
     def decimate(self, disp, scale=4):
         """torch CUDA int16 (n,H,W) or (H,W) -> every scale-th pixel, on the device."""
         import torch
