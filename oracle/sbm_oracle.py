@@ -96,7 +96,8 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = build()
+        override = os.environ.get("SBM_ORACLE_LIB")   # e.g. the sanitizer build, see oracle/Makefile
+        so = pathlib.Path(override).resolve() if override else build()
         try:
             L = ctypes.CDLL(str(so))
         except OSError:
