@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--no-postfilter", action="store_true", help="SAD/WTA/texture/uniqueness only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-profile", action="store_true", help="no stage events in the timed region (experiments)")
     ap.add_argument("--check", action="store_true", help="also verify pair 0 of rank 0 against the oracle")
     ap.add_argument("--gather", action="store_true",
                     help="N>1: also gather every step's disparity maps on rank 0 (RCCL) inside the timed region")
@@ -143,7 +144,7 @@ def main():
         bm.launch_raw(B, pl, pr, W, H, pd)
     sync_all()
 
-    bm.set_profiling(2)  # stage events recorded on the engine's stream, no host sync inside the timed region
+    bm.set_profiling(0 if args.no_profile else 2)  # stage events recorded on the engine's stream, no host sync inside the timed region
     sync_all()
     t0 = time.perf_counter()
     gathered = None

@@ -111,7 +111,13 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
 
 /* n pairs already resident in DEVICE memory, densely packed: left/right = n*height*width bytes,
  * disp = n*height*width int16. Asynchronous on the handle's stream unless `sync` is non-zero.
- * This is the entry point bench.py times (inputs resident in HBM when the timed region starts). */
+ * This is the entry point bench.py times (inputs resident in HBM when the timed region starts).
+ * Ordering: the handle's stream is a hipStreamNonBlocking stream -- it does NOT order behind the null stream or any
+ * other stream of the caller. The inputs must be complete before the call (synchronise the producing stream, or make
+ * sbm_stream() wait on an event of the producer with hipStreamWaitEvent), and with sync == 0 the buffers must stay
+ * alive and untouched until sbm_synchronize() or an event recorded on sbm_stream() after the call has completed.
+ * Internally the call forks helper streams (the border-column kernel runs underneath the interior SAD kernel);
+ * everything is joined back into the handle's stream before the call's work counts as finished. */
 int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, int width, int height,
                        void* d_disp, int sync);
 
@@ -125,11 +131,14 @@ int sbm_synchronize(sbm_handle* h);
 int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
 
 /* Per-stage device time in ms, measured with HIP events recorded on the handle's stream around each stage.
- * enabled = 1: every sbm_compute_device call synchronises and sbm_get_profile returns that call's times;
+ * enabled = 1: every sbm_compute_device call synchronises, stages run strictly one after the other (no sub-batch
+ *              pipeline) and sbm_get_profile returns the LAST call's times;
  * enabled = 2: events are recorded without synchronising (use inside a timed region) and sbm_get_profile
  *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
- * names: "prefilter", "sad" (fast SAD/WTA kernel), "border" (generic kernel on the clamped border columns, or on
- * everything when the fast path is off), "lrcheck", "speckle", "total". */
+ * names: "prefilter", "sad" (fast SAD/WTA kernel; every SAD launch of the call when it is pipelined), "border" (what
+ * is left of the border-column kernel after the interior kernel has finished; the generic kernel when the fast path
+ * is off), "lrcheck", "speckle", "total". (With the experimental sub-batch pipeline, SBM_SUBBATCH > 1, "border" and
+ * "lrcheck" read 0 and "speckle" is the post-filter tail left after the last SAD launch.) */
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
 
@@ -203,7 +212,9 @@ int sbm_rect_remap_device(sbm_handle* h, int n, const void* d_src, const void* d
 int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int height, int flavour, int cap,
                          void* d_dst, int sync);
 
-/* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours. */
+/* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours (record an event on it
+ * after sbm_compute_device(..., sync = 0)) or ours behind theirs (hipStreamWaitEvent on it before the call). Every entry
+ * point selects the handle's device for the duration of the call and restores the caller's current device on return. */
 void* sbm_stream(sbm_handle* h);
 
 const char* sbm_strerror(int code);

@@ -21,7 +21,13 @@ struct sbm_handle {
   int device;
   hipStream_t stream;
   hipStream_t stream2;   // side stream: the latency-bound border kernel overlaps the VALU-bound SAD kernel
+  hipStream_t stream3;   // post-filter stream of the sub-batch pipeline: LR check + speckle of sub-batch k run while the
+                         // SAD kernel of sub-batch k+1 owns the VALUs
+  hipStream_t stream4;   // second SAD stream (optional): consecutive SAD launches alternate so one ramps up while the
+                         // previous one drains
   hipEvent_t ev_fork, ev_join;
+  static constexpr int kMaxSub = 8;
+  hipEvent_t ev_sad[kMaxSub], ev_bord[kMaxSub], ev_post, ev_sad4;
   int last_hip;
   // scratch, sized for (cap_n, cap_W, cap_H, cap pitch)
   int cap_n, cap_W, cap_H, cap_pitch;
@@ -51,6 +57,17 @@ struct sbm_handle {
   bool ev_ok;
   unsigned calls;  // calls recorded since profiling was (re)enabled
   float ms_prefilter, ms_sad, ms_border, ms_lr, ms_speckle, ms_total;
+};
+
+// Entry points select the handle's device and put the caller's current device back on return.
+struct DeviceScope {
+  int prev, dev;
+  bool have;
+  explicit DeviceScope(int d) : prev(-1), dev(d), have(false) { have = hipGetDevice(&prev) == hipSuccess; }
+  hipError_t enter() { return (have && prev == dev) ? hipSuccess : hipSetDevice(dev); }
+  ~DeviceScope() {
+    if (have && prev != dev) hipSetDevice(prev);
+  }
 };
 
 #define HIPCHK(h, call)                         \
@@ -147,6 +164,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   size_t b = 2 * plane + npix * 2;
   if (h->cost) b += npix * 4;
   if (h->labels) b += npix * 8;
+  if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
   return b;
 }
@@ -185,20 +203,29 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
   memset(h, 0, sizeof(*h));
   h->p = *p;
   h->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+  DeviceScope dscope(device);
+  if (dscope.enter() != hipSuccess) {
     delete h;
     return SBM_ERR_NO_DEVICE;
   }
-  {
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-      hipStreamDestroy(h->stream);
-      delete h;
-      return SBM_ERR_HIP;
-    }
+  // every failure below goes through destroy_now(), which tolerates the members that were never created (null)
+  bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+  int lo = 0, hi = 0;
+  ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, hi) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_post, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_sad4, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < sbm_handle::kMaxSub; i++) {
+    ok = hipEventCreateWithFlags(&h->ev_sad[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_bord[i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) {
+    destroy_now(h);
+    return SBM_ERR_HIP;
   }
   h->ev_ok = true;
   for (int r = 0; r < sbm_handle::kRing; r++)
@@ -207,11 +234,20 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
   return SBM_OK;
 }
 
+static void sync_all_streams(sbm_handle* h) {
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream2) hipStreamSynchronize(h->stream2);
+  if (h->stream3) hipStreamSynchronize(h->stream3);
+  if (h->stream4) hipStreamSynchronize(h->stream4);
+  if (h->stream_in) hipStreamSynchronize(h->stream_in);
+  if (h->stream_out) hipStreamSynchronize(h->stream_out);
+}
+
 void sbm_destroy(sbm_handle* h) {
   if (!h) return;
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
-  hipStreamSynchronize(h->stream2);
+  DeviceScope dscope(h->device);
+  dscope.enter();
+  sync_all_streams(h);
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool_n < kPool) {
@@ -226,25 +262,35 @@ void sbm_destroy(sbm_handle* h) {
   destroy_now(h);
 }
 
+// Frees whatever the handle owns; members that were never created are null (the handle is zero-initialised), so this is
+// also the failure path of sbm_create. Restores the caller's current device.
 static void destroy_now(sbm_handle* h) {
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  DeviceScope dscope(h->device);
+  dscope.enter();
+  sync_all_streams(h);
   free_scratch(h);
   free_staging(h);
   for (int r = 0; r < sbm_handle::kRing; r++)
-    for (int i = 0; i < sbm_handle::kMarks; i++) hipEventDestroy(h->ev[r][i]);
-  if (h->pipe_ok) {
-    hipStreamSynchronize(h->stream_in);
-    hipStreamSynchronize(h->stream_out);
-    for (int i = 0; i < sbm_handle::kChunks; i++) { hipEventDestroy(h->ev_in[i]); hipEventDestroy(h->ev_done[i]); }
-    hipStreamDestroy(h->stream_in);
-    hipStreamDestroy(h->stream_out);
+    for (int i = 0; i < sbm_handle::kMarks; i++)
+      if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
+  for (int i = 0; i < sbm_handle::kChunks; i++) {
+    if (h->ev_in[i]) hipEventDestroy(h->ev_in[i]);
+    if (h->ev_done[i]) hipEventDestroy(h->ev_done[i]);
   }
-  hipStreamSynchronize(h->stream2);
-  hipEventDestroy(h->ev_fork);
-  hipEventDestroy(h->ev_join);
-  hipStreamDestroy(h->stream2);
-  hipStreamDestroy(h->stream);
+  if (h->stream_in) hipStreamDestroy(h->stream_in);
+  if (h->stream_out) hipStreamDestroy(h->stream_out);
+  for (int i = 0; i < sbm_handle::kMaxSub; i++) {
+    if (h->ev_sad[i]) hipEventDestroy(h->ev_sad[i]);
+    if (h->ev_bord[i]) hipEventDestroy(h->ev_bord[i]);
+  }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->ev_post) hipEventDestroy(h->ev_post);
+  if (h->ev_sad4) hipEventDestroy(h->ev_sad4);
+  if (h->stream4) hipStreamDestroy(h->stream4);
+  if (h->stream3) hipStreamDestroy(h->stream3);
+  if (h->stream2) hipStreamDestroy(h->stream2);
+  if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -265,7 +311,8 @@ int sbm_last_hip_error(const sbm_handle* h) { return h ? h->last_hip : 0; }
 
 int sbm_synchronize(sbm_handle* h) {
   if (!h) return SBM_ERR_NULL;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
 }
@@ -322,11 +369,13 @@ static inline void mark(sbm_handle* h, int i) {
   if (h->profiling && h->ev_ok) hipEventRecord(h->ev[h->calls % sbm_handle::kRing][i], h->stream);
 }
 
-// average stage times over the recorded calls (at most the last kRing); the stream must be idle
+// mode 2: average stage times over the recorded calls (at most the last kRing); mode 1: the last call only.
+// The stream must be idle.
 static void collect_profile(sbm_handle* h) {
-  const unsigned nrec = std::min<unsigned>(h->calls, sbm_handle::kRing);
+  unsigned nrec = std::min<unsigned>(h->calls, sbm_handle::kRing), first = 0;
+  if (h->profiling == 1 && h->calls > 0) { first = (h->calls - 1) % sbm_handle::kRing; nrec = 1; }
   float acc[5] = {0, 0, 0, 0, 0}, tot = 0.f;
-  for (unsigned r = 0; r < nrec; r++) {
+  for (unsigned r = first; r < first + nrec; r++) {
     for (int i = 0; i < 5; i++) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, h->ev[r][i], h->ev[r][i + 1]) == hipSuccess) acc[i] += ms;
@@ -348,7 +397,8 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   if (n > 32767 || height > 65535) return SBM_ERR_UNSUPPORTED;
   const sbm_params& p = h->p;
   if (p.num_disparities > 4096) return SBM_ERR_UNSUPPORTED;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
 
   Geom g;
   memset(&g, 0, sizeof(g));
@@ -367,7 +417,6 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   g.pitch = ((g.padl + width + 128 + 63) / 64) * 64;
   g.plane = g.pitch * height;
   int16_t* out = (int16_t*)d_disp;
-  const size_t npix = (size_t)n * width * height;
 
   int roi[4];
   valid_roi(p, width, height, roi);
@@ -382,63 +431,117 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   if (st != SBM_OK) return st;
   h->last = g; h->have_last = true;
 
+  // 16-bit cost plane when every producer is a 16-bit-sum kernel (fast interior + border kernels, w/2 clamped columns on
+  // each side); the generic kernel needs int32
+  const bool fast = any_rows && sad_fast_supported(g);
+  int fa = 0, fb = 0;
+  if (fast) {
+    const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
+    fa = g.w2; fb = xhi - g.w2 + 1;   // the interior range launch_sad_fast covers; xend - fb == w/2 by construction
+    g.cost16 = 1;
+  }
+  h->last = g;
+  // columns left and right of the fast range: clamped windows. They only matter if they can influence the output:
+  // through the LR check or when inside the valid ROI.
+  const bool borders_visible = g.want_cost || g.col0 < g.lofs + fa || g.col1 > g.lofs + fb;
+  static const int side_env = [] { const char* e = getenv("SBM_SIDE"); return e ? atoi(e) : 1; }();
+  const bool side = fast && borders_visible && side_env;   // border columns on the side stream, under the interior kernel
+  const bool border_inline = fast && borders_visible && !side_env;
+
+  // Sub-batch pipeline (OFF by default, SBM_SUBBATCH=k turns it on): SAD of sub-batch k+1 on the main stream while LR +
+  // speckle of sub-batch k run on a second high-priority stream. Measured on MI355X (round 2, KITTI 64 pairs,
+  // profiles/r02_subbatch_pipeline.md): 1.47 ms -> 1.54 (k=2) / 1.73 (k=4). The SAD kernel holds 4 wavefronts x 126
+  // VGPRs on every SIMD, so a post-filter wavefront can only start where a SAD workgroup has just retired: the kernel
+  // trace shows LR(k) starting with SAD(k+1) and finishing with it, and the smaller SAD launches lose more to their own
+  // tails than the overlap gives back. Kept for re-measurement when the SAD kernel's occupancy changes.
+  int nsub = 1;
+  {
+    static const int sub_env = [] { const char* e = getenv("SBM_SUBBATCH"); return e ? atoi(e) : 1; }();
+    const bool has_post = g.want_cost || speckle;
+    if (fast && has_post && h->profiling != 1 && sub_env > 1)
+      nsub = std::max(1, std::min(std::min(sub_env, (int)sbm_handle::kMaxSub), n));
+  }
+  static const int sad_streams = [] { const char* e = getenv("SBM_SAD_STREAMS"); return e ? atoi(e) : 1; }();
+  const uint8_t* dl = (const uint8_t*)d_left;
+  const uint8_t* dr = (const uint8_t*)d_right;
+  const size_t pix1 = (size_t)width * height;
+
   mark(h, 0);
   if (any_rows) {
     if (p.prefilter_type == SBM_PREFILTER_XSOBEL) {
-      HIPCHK(h, launch_prefilter((const uint8_t*)d_left, (const uint8_t*)d_right, h->pf_l, h->pf_r, g, h->stream));
+      HIPCHK(h, launch_prefilter(dl, dr, h->pf_l, h->pf_r, g, h->stream));
     } else {
       if (!h->vsum) HIPCHK(h, hipMalloc((void**)&h->vsum, (size_t)2 * h->cap_n * width * height * sizeof(uint16_t)));
-      HIPCHK(h, launch_prefilter_norm((const uint8_t*)d_left, (const uint8_t*)d_right, h->pf_l, h->pf_r, h->vsum, g,
-                                      p.prefilter_size, h->stream));
+      HIPCHK(h, launch_prefilter_norm(dl, dr, h->pf_l, h->pf_r, h->vsum, g, p.prefilter_size, h->stream));
     }
   }
   mark(h, 1);
-  if (any_rows) {
-    // every computed column (valid or not) must hold a defined value before the LR check reads it
-    int fa = 0, fb = 0;
-    // 16-bit cost plane when every producer is a 16-bit-sum kernel (fast + border); the generic kernel needs int32
-    {
-      const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
-      g.cost16 = sad_fast_supported(g) && g.xend - (xhi - g.w2 + 1) == g.w2;
-      h->last = g;
-    }
-    const bool fast = sad_fast_supported(g);
-    if (fast) {
-      const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
-      fa = g.w2; fb = xhi - g.w2 + 1;   // the interior range launch_sad_fast will cover
-    }
-    // columns left and right of the fast range: clamped windows (or everything when the fast path is off).
-    // They only matter if they can influence the output: through the LR check or when inside the valid ROI.
-    const bool borders_visible = g.want_cost || g.col0 < g.lofs + fa || g.col1 > g.lofs + fb;
-    const bool side = fast && borders_visible;   // border columns on the side stream, concurrently with the interior
-    if (side) {
-      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      if (fa == g.w2 && g.xend - fb == g.w2) {
+  if (nsub == 1) {
+    if (any_rows) {
+      if (side) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream2));
-      } else {
-        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, fa, h->stream2));
-        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fb, g.xend, h->stream2));
+        HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
       }
-      HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
-    }
-    if (fast) {
-      int xa = 0, xb = 0;
-      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
+      if (fast) {
+        int xa = 0, xb = 0;
+        if (border_inline) HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream));
+        HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
+      } else {
+        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
+      }
+      mark(h, 2);
+      if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     } else {
-      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
+      mark(h, 2);
     }
-    mark(h, 2);
-    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    mark(h, 3);
+    HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
+    mark(h, 4);
+    if (speckle) HIPCHK(h, launch_speckle(out, h->labels, h->counts, g, p.speckle_window_size, p.speckle_range, h->stream));
+    mark(h, 5);
   } else {
-    mark(h, 2);
+    // (nsub > 1 implies fast, hence any_rows)
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));                 // prefiltered planes are ready
+    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    const bool two = sad_streams > 1;
+    if (two) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_fork, 0));
+    const size_t cost_el = g.cost16 ? sizeof(uint16_t) : sizeof(int32_t);
+    for (int k = 0; k < nsub; k++) {
+      const int i0 = (int)((long)n * k / nsub), i1 = (int)((long)n * (k + 1) / nsub);
+      Geom gk = g;
+      gk.n = i1 - i0;
+      const uint8_t* pfl = h->pf_l + (size_t)i0 * g.plane;
+      const uint8_t* pfr = h->pf_r + (size_t)i0 * g.plane;
+      int16_t* dpre = h->disp_pre + i0 * pix1;
+      int32_t* costk = h->cost ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(h->cost) + i0 * pix1 * cost_el) : nullptr;
+      if (side) {
+        HIPCHK(h, launch_sad_border(pfl, pfr, dpre, costk, gk, fa, fb, h->stream2));
+        HIPCHK(h, hipEventRecord(h->ev_bord[k], h->stream2));
+      }
+      hipStream_t ss = (two && (k & 1)) ? h->stream4 : h->stream;
+      int xa = 0, xb = 0;
+      HIPCHK(h, launch_sad_fast(pfl, pfr, dpre, costk, gk, &xa, &xb, ss));
+      HIPCHK(h, hipEventRecord(h->ev_sad[k], ss));
+      HIPCHK(h, hipStreamWaitEvent(h->stream3, h->ev_sad[k], 0));
+      if (side) HIPCHK(h, hipStreamWaitEvent(h->stream3, h->ev_bord[k], 0));
+      HIPCHK(h, launch_lrcheck(dpre, costk, out + i0 * pix1, gk, p.disp12_max_diff, h->stream3));
+      if (speckle)
+        HIPCHK(h, launch_speckle(out + i0 * pix1, h->labels + i0 * pix1, h->counts + i0 * pix1, gk, p.speckle_window_size,
+                                 p.speckle_range, h->stream3));
+    }
+    if (two) {
+      HIPCHK(h, hipEventRecord(h->ev_sad4, h->stream4));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sad4, 0));
+    }
+    mark(h, 2);   // "sad" = all SAD launches of the call (post-filters of earlier sub-batches run underneath)
+    mark(h, 3);
+    mark(h, 4);
+    HIPCHK(h, hipEventRecord(h->ev_post, h->stream3));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_post, 0));
+    mark(h, 5);   // "speckle" = the exposed tail: border/LR/speckle work still running when the last SAD launch ends
   }
-  mark(h, 3);
-  HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
-  mark(h, 4);
-  if (speckle) HIPCHK(h, launch_speckle(out, h->labels, h->counts, g, p.speckle_window_size, p.speckle_range, h->stream));
-  mark(h, 5);
-  (void)npix;
   if (h->profiling) h->calls++;
   if (sync || h->profiling == 1) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
@@ -447,7 +550,8 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
 int sbm_rect_map_device(sbm_handle* h, const sbm_rect_cam* cam, int width, int height, void* d_map, int sync) {
   if (!h || !cam || !d_map) return SBM_ERR_NULL;
   if (width <= 0 || height <= 0 || width > 32767 || height > 32767) return SBM_ERR_SIZE;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_rect_map(*cam, width, height, (int16_t*)d_map, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
@@ -459,7 +563,8 @@ int sbm_rect_remap_device(sbm_handle* h, int n, const void* d_src, const void* d
   if (n <= 0) return SBM_ERR_BATCH;
   if (width <= 0 || height <= 0 || width > 32767 || height > 32767) return SBM_ERR_SIZE;
   if (((size_t)width * height + 1023) / 1024 > 65535) return SBM_ERR_UNSUPPORTED;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_rect_remap((const uint8_t*)d_src, (const int16_t*)d_map, (uint8_t*)d_dst, n, width, height, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
@@ -473,7 +578,8 @@ int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int
   if (flavour != SBM_PREFILTER_FLAVOUR_CV && flavour != SBM_PREFILTER_FLAVOUR_RTL) return SBM_ERR_PREFILTER_TYPE;
   if (flavour == SBM_PREFILTER_FLAVOUR_CV && (cap < 1 || cap > 63)) return SBM_ERR_PREFILTER_CAP;
   if (n > 65534 || height > 65535 * 4) return SBM_ERR_UNSUPPORTED;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_src, (uint8_t*)d_dst, n, width, height,
                                    flavour == SBM_PREFILTER_FLAVOUR_RTL, cap, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -484,7 +590,8 @@ int sbm_disparity_to_float_device(sbm_handle* h, int n, const void* d_disp, int 
   if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;
   if (width <= 0 || height <= 0) return SBM_ERR_SIZE;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_disp_to_float((const int16_t*)d_disp, (float*)d_out, (size_t)n * width * height, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
@@ -494,7 +601,8 @@ int sbm_decimate_device(sbm_handle* h, int n, const void* d_disp, int width, int
   if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;
   if (width <= 0 || height <= 0 || scale <= 0) return SBM_ERR_SIZE;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_decimate((const int16_t*)d_disp, (int16_t*)d_out, n, width, height, scale, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
@@ -505,7 +613,8 @@ int sbm_reproject_device(sbm_handle* h, int n, const void* d_disp, int width, in
   if (!h || !d_disp || !d_xyz || !model) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;
   if (width <= 0 || height <= 0 || scale <= 0) return SBM_ERR_SIZE;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_reproject((const int16_t*)d_disp, (float*)d_xyz, n, width, height, scale, *model, apply_local, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
@@ -515,7 +624,8 @@ int sbm_keypoints3d_device(sbm_handle* h, const void* d_disp, int width, int hei
                            const sbm_stereo_model* model, float min_depth, float max_depth, void* d_xyz, int sync) {
   if (!h || !d_disp || !model || (nk > 0 && (!d_kpts || !d_xyz))) return SBM_ERR_NULL;
   if (width <= 0 || height <= 0 || nk < 0) return SBM_ERR_SIZE;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_keypoints3d((const int16_t*)d_disp, (const float*)d_kpts, (float*)d_xyz, width, height, nk, *model,
                                min_depth, max_depth, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -524,7 +634,8 @@ int sbm_keypoints3d_device(sbm_handle* h, const void* d_disp, int width, int hei
 
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms) {
   if (!h || !name || !ms) return SBM_ERR_NULL;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->profiling && h->ev_ok) collect_profile(h);
   if (!strcmp(name, "prefilter")) *ms = h->ms_prefilter;
@@ -541,7 +652,8 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes) {
   if (!h || !dst) return SBM_ERR_NULL;
   if (!h->have_last) return SBM_ERR_UNSUPPORTED;
   const Geom& g = h->last;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const size_t npix = (size_t)g.n * g.W * g.H;
   if (which == 0 || which == 1) {
@@ -613,15 +725,12 @@ static int ensure_pipe(sbm_handle* h) {
 // works on chunk k while chunk k+1 arrives and chunk k-1 leaves. With pageable caller memory the copies themselves still
 // run one after the other on the calling thread (the runtime stages them), but the compute disappears behind them; with
 // pinned (hipHostMalloc / hipHostRegister) caller memory the two copy directions overlap as well.
-static int compute_batch_pipelined(sbm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int width,
-                                   int height, int16_t* const* disp) {
-  int st = ensure_pipe(h);
-  if (st != SBM_OK) return st;
+static int pipelined_enqueue(sbm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int width,
+                             int height, int16_t* const* disp) {
   const size_t npix1 = (size_t)width * height;
   int chunk = 8;
   while ((n + chunk - 1) / chunk > sbm_handle::kChunks) chunk *= 2;
   const int nch = (n + chunk - 1) / chunk;
-  HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffers of an earlier call are free
   for (int k = 0; k < nch; k++) {
     const int i0 = k * chunk, cnt = std::min(chunk, n - i0);
     for (int i = i0; i < i0 + cnt; i++) {
@@ -630,7 +739,7 @@ static int compute_batch_pipelined(sbm_handle* h, int n, const uint8_t* const* l
     }
     HIPCHK(h, hipEventRecord(h->ev_in[k], h->stream_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[k], 0));
-    st = sbm_compute_device(h, cnt, h->st_l + i0 * npix1, h->st_r + i0 * npix1, width, height, h->st_d + i0 * npix1, 0);
+    const int st = sbm_compute_device(h, cnt, h->st_l + i0 * npix1, h->st_r + i0 * npix1, width, height, h->st_d + i0 * npix1, 0);
     if (st != SBM_OK) return st;
     HIPCHK(h, hipEventRecord(h->ev_done[k], h->stream));
     if (k > 0) {   // the previous chunk leaves while this one computes
@@ -643,8 +752,22 @@ static int compute_batch_pipelined(sbm_handle* h, int n, const uint8_t* const* l
   HIPCHK(h, hipStreamWaitEvent(h->stream_out, h->ev_done[nch - 1], 0));
   for (int i = (nch - 1) * chunk; i < n; i++)
     HIPCHK(h, hipMemcpyAsync(disp[i], h->st_d + i * npix1, npix1 * 2, hipMemcpyDeviceToHost, h->stream_out));
-  HIPCHK(h, hipStreamSynchronize(h->stream_out));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+static int compute_batch_pipelined(sbm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int width,
+                                   int height, int16_t* const* disp) {
+  int st = ensure_pipe(h);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffers of an earlier call are free
+  st = pipelined_enqueue(h, n, left, right, width, height, disp);
+  // success or not: nothing may still be reading or writing the caller's buffers when this returns
+  const hipError_t e1 = hipStreamSynchronize(h->stream_in), e2 = hipStreamSynchronize(h->stream),
+                   e3 = hipStreamSynchronize(h->stream_out);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, e1);
+  HIPCHK(h, e2);
+  HIPCHK(h, e3);
   return SBM_OK;
 }
 
@@ -657,7 +780,8 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
   if (left_stride < (size_t)width || right_stride < (size_t)width || disp_stride < (size_t)width * 2) return SBM_ERR_SIZE;
   for (int i = 0; i < n; i++)
     if (!left[i] || !right[i] || !disp[i]) return SBM_ERR_NULL;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
   st = ensure_staging(h, n, width, height);
   if (st != SBM_OK) return st;
   const size_t npix1 = (size_t)width * height;
