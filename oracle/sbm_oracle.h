@@ -100,6 +100,30 @@ void sbmo_keypoints3d(const int16_t* disp, int width, int height, const float* k
 void sbmo_rect_map(const sbm_rect_cam* cam, int width, int height, int16_t* map);
 void sbmo_rect_remap(const uint8_t* src, const int16_t* map, int width, int height, uint8_t* dst);
 
+/* ---- FPGA flavour of the matcher, sbm_oracle_fpga.c. PARITY UNPINNED: restated from
+ * the RTL (src/dvp/rtl/bm_calc_sad.v, bm_calc_det.v, bm_calc_frac.v, bm_calc_upd.v, bm_calc_uni.v, bm_calc.v, bm_obuf2.v,
+ * diven.v, scheduling bm_ibuf.v:143-286); the reference holds the RTL's stimulus (data/ref_xsbl_*) but no output. */
+/* diven.v with parameters (DW, VW, QW, MSB_INV): the pipelined non-restoring divider, bit-serially. */
+uint32_t sbmo_rtl_diven(int DW, int VW, int QW, int MSB_INV, uint32_t dividend, uint32_t divisor);
+/* bm_calc_det.v: sad[0] and sad[33] are the guard lanes, the minimum is searched over sad[1..32] (idx 0..31). */
+void sbmo_rtl_det(const uint16_t sad[34], uint16_t* min1, uint16_t* min2, int* idx1, int* idx2, uint16_t* det_l,
+                  uint16_t* det_r);
+/* bm_calc_frac.v: signed 8-bit sub-pixel fraction (s-1.8) from centre / left (D-1) / right (D+1) SADs. */
+uint8_t sbmo_rtl_frac(uint16_t c, uint16_t l, uint16_t r);
+/* bm_obuf2.v:119-154: (integer disparity, fraction) -> s11.4, 0xFFFF when negative or zero. */
+int16_t sbmo_rtl_pack_disparity(uint8_t disp, uint8_t frac);
+/* struct FPGA_REG_BM (src/StereoBM/src/fpga.h:154-169) as decoded by bm.v:172-193:
+ * out = {wdt, hgt, wsz, ndisp, uni_enb, uni_mode, uni_thr}. */
+int sbmo_fpga_regs_decode(uint32_t image_size, uint32_t bm_setting, uint32_t uni_filt_ctrl, int32_t out[7]);
+/* Limits of the RTL (field widths, whole 32-disparity phases, odd window) as SBM_* status codes. */
+int sbmo_fpga_check(int width, int height, int wsz, int ndisp);
+/* The matcher on dense x-Sobel planes (what data/ref_xsbl_{l,r} are); disp dense int16, fully written (-1 = none). */
+int sbmo_fpga_bm(const uint8_t* xl, const uint8_t* xr, int width, int height, int wsz, int ndisp, int uni_enb,
+                 int uni_mode, int uni_thr, int16_t* disp);
+/* xsbl2.v prefilter of both rectified images (rows 0 / H-1 = 0) followed by the matcher. */
+int sbmo_fpga_compute(const uint8_t* left, const uint8_t* right, int width, int height, int wsz, int ndisp, int uni_enb,
+                      int uni_mode, int uni_thr, int16_t* disp);
+
 int sbmo_max_threads(void);
 
 #ifdef __cplusplus

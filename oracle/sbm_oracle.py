@@ -87,8 +87,8 @@ def make_params(num_disparities=64, block_size=21, prefilter_cap=31, min_dispari
 
 def build(force=False):
     so = _HERE / "libsbm_oracle.so"
-    src = _HERE / "sbm_oracle.c"
-    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+    srcs = [_HERE / "sbm_oracle.c", _HERE / "sbm_oracle_fpga.c", _HERE / "sbm_oracle.h"]
+    if force or not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
         subprocess.run(["make", "-C", str(_HERE), "libsbm_oracle.so"], check=True, capture_output=True)
     return so
 
@@ -137,6 +137,23 @@ def lib():
         L.sbmo_rect_map.restype = None
         L.sbmo_rect_remap.argtypes = [u8p, i16p, ci, ci, u8p]
         L.sbmo_rect_remap.restype = None
+        u16p, u32 = ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32
+        L.sbmo_rtl_diven.argtypes = [ci, ci, ci, ci, u32, u32]
+        L.sbmo_rtl_diven.restype = u32
+        L.sbmo_rtl_det.argtypes = [u16p, u16p, u16p, ctypes.POINTER(ci), ctypes.POINTER(ci), u16p, u16p]
+        L.sbmo_rtl_det.restype = None
+        L.sbmo_rtl_frac.argtypes = [ctypes.c_uint16] * 3
+        L.sbmo_rtl_frac.restype = ctypes.c_uint8
+        L.sbmo_rtl_pack_disparity.argtypes = [ctypes.c_uint8, ctypes.c_uint8]
+        L.sbmo_rtl_pack_disparity.restype = ctypes.c_int16
+        L.sbmo_fpga_regs_decode.argtypes = [u32, u32, u32, i32p]
+        L.sbmo_fpga_regs_decode.restype = ci
+        L.sbmo_fpga_check.argtypes = [ci, ci, ci, ci]
+        L.sbmo_fpga_check.restype = ci
+        L.sbmo_fpga_bm.argtypes = [u8p, u8p, ci, ci, ci, ci, ci, ci, ci, i16p]
+        L.sbmo_fpga_bm.restype = ci
+        L.sbmo_fpga_compute.argtypes = [u8p, u8p, ci, ci, ci, ci, ci, ci, ci, i16p]
+        L.sbmo_fpga_compute.restype = ci
         _LIB = L
     return _LIB
 
@@ -303,3 +320,59 @@ def rect_remap(src, rmap):
     out = np.empty((h, w), np.uint8)
     lib().sbmo_rect_remap(_p(src, ctypes.c_uint8), _p(rmap, ctypes.c_int16), w, h, _p(out, ctypes.c_uint8))
     return out
+
+
+# ---- FPGA flavour of the matcher (sbm_oracle_fpga.c; parity unpinned, restated from src/dvp/rtl/bm*.v) ----------------
+def rtl_diven(DW, VW, QW, MSB_INV, dividend, divisor):
+    return int(lib().sbmo_rtl_diven(DW, VW, QW, MSB_INV, dividend & 0xffffffff, divisor & 0xffffffff))
+
+
+def rtl_det(sad34):
+    a = np.ascontiguousarray(sad34, dtype=np.uint16)
+    assert a.shape == (34,)
+    m1, m2, l, r = (ctypes.c_uint16() for _ in range(4))
+    i1, i2 = ctypes.c_int(), ctypes.c_int()
+    lib().sbmo_rtl_det(_p(a, ctypes.c_uint16), ctypes.byref(m1), ctypes.byref(m2), ctypes.byref(i1), ctypes.byref(i2),
+                       ctypes.byref(l), ctypes.byref(r))
+    return dict(min1=m1.value, min2=m2.value, idx1=i1.value, idx2=i2.value, l=l.value, r=r.value)
+
+
+def rtl_frac(c, l, r):
+    return int(lib().sbmo_rtl_frac(c, l, r))
+
+
+def rtl_pack_disparity(disp, frac):
+    return int(lib().sbmo_rtl_pack_disparity(disp & 0xff, frac & 0xff))
+
+
+def fpga_regs_decode(image_size, bm_setting, uni_filt_ctrl=0):
+    o = (ctypes.c_int32 * 7)()
+    lib().sbmo_fpga_regs_decode(image_size, bm_setting, uni_filt_ctrl, o)
+    return dict(zip(("width", "height", "block_size", "num_disparities", "uni_enable", "uni_mode", "uni_threshold"), o))
+
+
+def fpga_check(width, height, wsz, ndisp):
+    return int(lib().sbmo_fpga_check(width, height, wsz, ndisp))
+
+
+def fpga_bm(xl, xr, wsz, ndisp, uni_enb=0, uni_mode=0, uni_thr=0):
+    """The RTL matcher on x-Sobel planes (uint8, 6 significant bits). int16 (H,W), -1 where there is no disparity."""
+    xl, xr = _u8(xl), _u8(xr)
+    h, w = xl.shape
+    d = np.empty((h, w), np.int16)
+    st = lib().sbmo_fpga_bm(_p(xl, ctypes.c_uint8), _p(xr, ctypes.c_uint8), w, h, wsz, ndisp, uni_enb, uni_mode, uni_thr,
+                            _p(d, ctypes.c_int16))
+    if st != 0:
+        raise ValueError(f"oracle status {st}")
+    return d
+
+
+def fpga_compute(left, right, wsz, ndisp, uni_enb=0, uni_mode=0, uni_thr=0):
+    left, right = _u8(left), _u8(right)
+    h, w = left.shape
+    d = np.empty((h, w), np.int16)
+    st = lib().sbmo_fpga_compute(_p(left, ctypes.c_uint8), _p(right, ctypes.c_uint8), w, h, wsz, ndisp, uni_enb, uni_mode,
+                                 uni_thr, _p(d, ctypes.c_int16))
+    if st != 0:
+        raise ValueError(f"oracle status {st}")
+    return d

@@ -1,0 +1,259 @@
+"""CPU tests of the FPGA-flavour matcher oracle (oracle/sbm_oracle_fpga.c).
+
+The reference holds the RTL's stimulus (data/ref_xsbl_*) but no disparity output and no simulator runs here, so this
+stage is PARITY UNPINNED. What can be checked: the C restatement against a second, independently structured restatement
+of the same RTL statements (numpy, whole-array formulation, written from the Verilog and not from the C), the building
+blocks against their definitions, the firmware's register constants, and the geometry the RTL fixes.
+"""
+import numpy as np
+import pytest
+
+
+# ---- independent restatement (numpy) ---------------------------------------------------------------------------------
+def py_diven(DW, VW, QW, MSB_INV, dividend, divisor):
+    """diven.v, from the Verilog: non-restoring divider on Python integers (two's complement by masking)."""
+    ext_rem, ext_div = VW - MSB_INV, DW - MSB_INV - 1
+    RW = DW - ext_div if ext_div < 0 else DW + ext_rem
+    EVW = VW if ext_div < 0 else VW + ext_div
+    div = (divisor & ((1 << VW) - 1)) << max(ext_div, 0)
+    dvd = dividend & ((1 << DW) - 1)
+    if ext_div < 0:
+        dvd <<= -ext_div
+    elif dvd >> (DW - 1):
+        dvd -= 1 << DW                      # signed value
+    dvd &= (1 << RW) - 1
+    sdiv = div >> (EVW - 1)
+    sdivv = div - (1 << EVW) if sdiv else div   # signed divisor
+
+    def step(rem, op):
+        r = rem - (1 << RW) if rem >> (RW - 1) else rem
+        r = 2 * r + 2 * sdivv if op else 2 * r - 2 * sdivv
+        return r & ((1 << RW) - 1)
+
+    op = sdiv ^ (dvd >> (RW - 1))
+    rem = step(dvd, op)
+    q = 0
+    for _ in range(QW):
+        op = sdiv ^ (rem >> (RW - 1))
+        rem = step(rem, op)
+        q = ((q << 1) | (1 - op)) & ((1 << QW) - 1)
+    return (q + sdiv) & ((1 << QW) - 1)
+
+
+def py_det(sad):
+    """bm_calc_det.v as a recursive knock-out tournament over lanes 1..32 (lower lane wins ties)."""
+    def play(lo, hi):                       # returns winner lane, and the list of (value, lane) it beat on the way, last first
+        if hi - lo == 1:
+            return lo, []
+        mid = (lo + hi) // 2
+        a, la = play(lo, mid)
+        b, lb = play(mid, hi)
+        if sad[b] < sad[a]:
+            return b, [(sad[a], a, la)] + lb
+        return a, [(sad[b], b, lb)] + la
+    w, beaten = play(1, 33)
+    # beaten[0] = loser of the final (the other half's winner), with the list of what IT beat
+    final_loser = beaten[0]
+    cand0 = (final_loser[0], final_loser[1])
+    # semi-final losers: the one the winner beat in its half's final, and the one the final's loser beat in its own
+    semi_w = beaten[1]
+    semi_l = final_loser[2][0]
+    # RTL order: min2_r4[0] belongs to lanes 1..16, min2_r4[1] to lanes 17..32; [1] only wins when strictly smaller
+    s = sorted([(semi_w[0], semi_w[1]), (semi_l[0], semi_l[1])], key=lambda t: t[1])
+    cand1 = s[1] if s[1][0] < s[0][0] else s[0]
+    i1 = w - 1
+    adj = lambda c: (c[1] - 1 == i1 + 1) or (i1 == c[1] - 1 + 1)
+    pick1 = (cand1[0] < cand0[0] and not adj(cand1)) or adj(cand0)
+    m2 = cand1 if pick1 else cand0
+    return dict(min1=int(sad[w]), idx1=i1, l=int(sad[w - 1]), r=int(sad[w + 1]), min2=int(m2[0]), idx2=m2[1] - 1)
+
+
+def py_frac(c, l, r):
+    if l < c or r < c:
+        num = 0
+    else:
+        num = l - r
+    den = 2 * ((l if l >= r else r) - c)
+    den &= (1 << 18) - 1
+    if den == 0:
+        return 0xC0 if l >= r else 0x40
+    return py_diven(18, 18, 8, 17, num & ((1 << 18) - 1), den)
+
+
+def py_pack(disp, frac):
+    f = frac - 256 if frac >= 128 else frac
+    depth = disp * 256 + f
+    if depth <= 0:
+        return -1
+    v = (depth >> 4) & 0xfff
+    if depth & 0x8000:
+        v |= 0xf000
+    return v - 65536 if v >= 32768 else v
+
+
+def py_fpga_bm(xl, xr, wsz, ndisp, uni_enb=0, uni_mode=0, uni_thr=0):
+    H, W = xl.shape
+    hw = wsz // 2
+    nc = W - ndisp - 1
+    L = (xl & 63).astype(np.int64)
+    R = (xr & 63).astype(np.int64)
+    D = np.arange(-1, ndisp + 1)
+    x = ndisp + np.arange(nc)
+    ad = np.abs(R[:, (x[:, None] - D[None, :])] - L[:, x][:, :, None])          # [H][nc][ndisp+2]
+    out = np.full((H, W), -1, np.int16)
+    state = None
+    rec = {}
+    for r in range(H - 2 * hw):
+        if r == 0:
+            state = ad[0].copy()
+            for y in range(1, wsz):
+                state = np.minimum(state + ad[y], 1023)
+        else:
+            state = np.minimum(np.maximum(state - ad[r - 1], 0) + ad[r + wsz - 1], 1023)
+        cs = np.concatenate([np.zeros((1, ndisp + 2), np.int64), np.cumsum(state, axis=0)])
+        sad_all = np.minimum(cs[wsz:] - cs[:-wsz], 65535)                         # [nc-2hw][ndisp+2]
+        for i in range(nc - 2 * hw):
+            cur = None
+            for k in range(ndisp // 32):
+                lanes = sad_all[i, 32 * k: 32 * k + 34]
+                d = py_det(lanes)
+                fr = py_frac(d["min1"], d["l"], d["r"])
+                d1, d2 = 32 * k + d["idx1"], 32 * k + d["idx2"]
+                if cur is None:
+                    cur = dict(min1=d["min1"], min2=d["min2"], disp1=d1, disp2=d2, frac=fr)
+                    continue
+                s = cur
+                adj = d1 == ((s["disp1"] + 1) & 255)
+                order = sorted([(d["min1"], 1, "d1"), (d["min2"], 1, "d2"), (s["min1"], 0, "s1"), (s["min2"], 0, "s2")])
+                # bm_calc_upd.v:125-142: the stored pair wins ties (strict '<' for the new pair), d1 <= d2 and s1 <= s2
+                # keep their relative order; the table only ever looks at the first three places
+                names = [t[2] for t in order]
+                # normalise impossible orders produced by equal keys (d2 before d1 / s2 before s1)
+                def fix(a, b):
+                    ia, ib = names.index(a), names.index(b)
+                    if ib < ia:
+                        names[ia], names[ib] = names[ib], names[ia]
+                fix("d1", "d2"); fix("s1", "s2")
+                val = dict(d1=(d["min1"], d1), d2=(d["min2"], d2), s1=(s["min1"], s["disp1"]), s2=(s["min2"], s["disp2"]))
+                first, second, third = names[0], names[1], names[2]
+                new = dict(cur)
+                if first == "d1":
+                    new["min1"], new["disp1"], new["frac"] = d["min1"], d1, fr
+                    if second == "d2":
+                        new["min2"], new["disp2"] = val["d2"]
+                    else:                                            # second is s1
+                        pick = second if not adj else third
+                        new["min2"], new["disp2"] = val[pick]
+                else:                                                # first is s1
+                    if second == "d1":
+                        pick = second if not adj else third
+                        new["min2"], new["disp2"] = val[pick]
+                cur = new
+            od, of = cur["disp1"], cur["frac"]
+            if uni_enb:
+                ratio = py_diven(17, 17, 11, 16, cur["min1"], cur["min2"]) & 1023
+                if ratio > uni_thr:
+                    od = of = 255 if uni_mode else 0
+            out[hw + r, ndisp + hw + 1 + i] = py_pack(od, of)
+    return out
+
+
+# ---- tests -------------------------------------------------------------------------------------------------------------
+def test_diven_against_independent_and_real_division(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(3000):
+        c = int(rng.integers(0, 30000))
+        l, r = c + int(rng.integers(0, 2500)), c + int(rng.integers(0, 2500))
+        den = 2 * (max(l, r) - c)
+        got = oracle.rtl_frac(c, l, r)
+        assert got == py_frac(c, l, r)
+        if den:
+            gs = got - 256 if got >= 128 else got
+            assert abs(gs - (l - r) / den * 128) <= 1.0     # quotient = ratio in 1/128 units (bm_obuf2 reads it as /256)
+    for _ in range(3000):
+        a, b = int(rng.integers(0, 65536)), int(rng.integers(0, 65536))
+        q = oracle.rtl_diven(17, 17, 11, 16, a, b)
+        assert q == py_diven(17, 17, 11, 16, a, b)
+        if b and a <= b:
+            assert abs(q - a / b * 1024) <= 1.0
+    assert oracle.rtl_diven(17, 17, 11, 16, 100, 100) == 1024      # ratio 1.0 overflows the 10 bits bm_calc_uni keeps
+
+
+def test_det_matches_tournament_and_definitions(oracle):
+    rng = np.random.default_rng(11)
+    for t in range(4000):
+        hi = [4, 40, 3000, 65535][t % 4]                    # small ranges force ties
+        sad = rng.integers(0, hi + 1, 34).astype(np.uint16)
+        got = oracle.rtl_det(sad)
+        assert got == py_det(sad), (sad, got, py_det(sad))
+        body = sad[1:33]
+        assert got["min1"] == body.min() and got["idx1"] == int(np.argmin(body))       # first minimum
+        assert got["l"] == sad[got["idx1"]] and got["r"] == sad[got["idx1"] + 2]
+        assert got["min2"] >= got["min1"] and got["idx2"] != got["idx1"]
+
+
+def test_pack_disparity(oracle):
+    for disp in (0, 1, 5, 63, 127, 128, 200, 255):
+        for frac in (0, 1, 0x3f, 0x40, 0x7f, 0x80, 0xc0, 0xff):
+            assert oracle.rtl_pack_disparity(disp, frac) == py_pack(disp, frac), (disp, frac)
+    assert oracle.rtl_pack_disparity(0, 0) == -1 and oracle.rtl_pack_disparity(0, 0xff) == -1
+    assert oracle.rtl_pack_disparity(51, 0x40) == (51 * 256 + 64) >> 4
+
+
+def test_register_decode_of_the_firmware_constants(oracle):
+    # src/StereoBM/src/fpga.c:155,158: ImageSize = (IMAGE_HEIGHT << 16) + IMAGE_WIDTH, BmSetting = 0x00150040
+    d = oracle.fpga_regs_decode((480 << 16) + 640, 0x00150040, 0)
+    assert d == dict(width=640, height=480, block_size=21, num_disparities=64, uni_enable=0, uni_mode=0, uni_threshold=0)
+    d = oracle.fpga_regs_decode((375 << 16) + 1000, (15 << 16) | 128, (1 << 31) | (1 << 16) | 0x2aa)
+    assert d == dict(width=1000, height=375, block_size=15, num_disparities=128, uni_enable=1, uni_mode=1, uni_threshold=0x2aa)
+    assert oracle.fpga_check(640, 480, 21, 64) == 0
+    assert oracle.fpga_check(640, 480, 20, 64) == -6 and oracle.fpga_check(640, 480, 21, 48) == -7
+    assert oracle.fpga_check(1024, 480, 21, 64) == -2 and oracle.fpga_check(85, 480, 21, 64) == -2
+
+
+@pytest.mark.parametrize("W,H,wsz,nd,amp", [(70, 14, 5, 32, 64), (110, 16, 7, 64, 64), (150, 12, 9, 96, 64),
+                                            (90, 30, 21, 32, 2), (84, 26, 21, 32, 64)])
+def test_matcher_against_independent_restatement(oracle, W, H, wsz, nd, amp):
+    rng = np.random.default_rng(W * 1000 + wsz)
+    if amp == 2:        # only 0 / 63: column sums of 21 rows exceed 1023 -> the 10-bit saturation path is exercised
+        xl = (rng.integers(0, 2, (H, W)) * 63).astype(np.uint8)
+        xr = (rng.integers(0, 2, (H, W)) * 63).astype(np.uint8)
+        xr[:, ::3] = 63 - xl[:, ::3]
+    else:
+        xr = rng.integers(0, amp, (H, W)).astype(np.uint8)
+        xl = np.roll(xr, 7, axis=1) if wsz != 9 else rng.integers(0, amp, (H, W)).astype(np.uint8)
+        xl = np.clip(xl.astype(int) + rng.integers(-3, 4, (H, W)), 0, 63).astype(np.uint8)
+    got = oracle.fpga_bm(xl, xr, wsz, nd)
+    ref = py_fpga_bm(xl, xr, wsz, nd)
+    assert np.array_equal(got, ref), np.argwhere(got != ref)[:5]
+    if amp == 2:
+        assert (got != -1).any()
+    # uniqueness filter on, both mask modes
+    for mode in (0, 1):
+        g2 = oracle.fpga_bm(xl, xr, wsz, nd, 1, mode, 0x300)
+        r2 = py_fpga_bm(xl, xr, wsz, nd, 1, mode, 0x300)
+        assert np.array_equal(g2, r2)
+
+
+def test_geometry_and_known_answer(oracle, golden):
+    """Invalid border widths of bm_obuf2.v:125 / 232-262 and a constant-shift known answer."""
+    H, W, wsz, nd, shift = 40, 200, 9, 64, 23
+    rng = np.random.default_rng(3)
+    xr = rng.integers(0, 64, (H, W)).astype(np.uint8)
+    xl = np.roll(xr, shift, axis=1)
+    d = oracle.fpga_bm(xl, xr, wsz, nd)
+    hw = wsz // 2
+    valid = np.zeros((H, W), bool)
+    valid[hw:H - hw, nd + hw + 1:W - hw] = True
+    assert (d[~valid] == -1).all()
+    # L(x) = R(x - shift): SAD is 0 at D = shift; the fraction (L-R)/(4*max(L,R)) stays within +-0.25 px = +-4 units
+    inner = d[hw:H - hw, nd + hw + 1:W - hw].astype(int)
+    assert (np.abs(inner - shift * 16) <= 4).all() and {shift * 16 - 1, shift * 16} <= set(np.unique(inner))
+    # on the reference's own stimulus: plausible map (SURVEY 8c sanity: foreground around 51 px)
+    dd = oracle.fpga_bm(golden["xsbl_l"], golden["xsbl_r"], 21, 64)
+    assert dd.shape == (480, 640) and (dd[:10] == -1).all() and (dd[:, :75] == -1).all() and (dd[:, 630:] == -1).all()
+    v = dd[dd != -1]
+    assert 0.5 < (dd != -1).mean() < 0.9 and 40 < np.median(v) / 16 < 60
+    # end-to-end entry: x-Sobel of the rectified pair (== golden xsbl) then the matcher
+    de = oracle.fpga_compute(golden["rect_l"], golden["rect_r"], 21, 64)
+    assert np.array_equal(de, dd)
