@@ -54,6 +54,55 @@ def usable_cores():
     return n
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one child process per GPU (this process never touches the
+    GPU, so nothing is exec'ed or forked after HIP initialisation), pass rank 0's JSON line through, fail if any rank
+    fails. Equivalent to `python -m torch.distributed.run --nproc-per-node N bench.py ...`, which still works."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(pathlib.Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in procs:          # a dead rank leaves the others waiting in a collective: stop exactly those PIDs
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+def probe_opencv():
+    """SURVEY.md 8c / BASELINE.md 3.1: use the real cv::StereoBM as checker and CPU baseline if this host has it."""
+    try:
+        import cv2  # noqa: F401
+
+        return cv2, f"cv2 {cv2.__version__}"
+    except Exception as e:  # noqa: BLE001
+        import ctypes.util
+
+        lib = ctypes.util.find_library("opencv_calib3d")
+        why = f"import cv2 failed ({type(e).__name__})"
+        if lib:
+            return None, f"unavailable: {why}; {lib} exists but cv::StereoBM has no C ABI to bind"
+        return None, f"unavailable: {why}; no libopencv_calib3d on the loader path"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +118,13 @@ def main():
     ap.add_argument("--check", action="store_true", help="also verify pair 0 of rank 0 against the oracle")
     ap.add_argument("--gather", action="store_true",
                     help="N>1: also gather every step's disparity maps on rank 0 (RCCL) inside the timed region")
+    ap.add_argument("--scatter", action="store_true",
+                    help="N>1: the whole global batch starts on rank 0; every step scatters it in chunks of --chunk pairs, "
+                         "computes and gathers the maps back (double-buffered point-to-point over RCCL), all inside the timed region")
+    ap.add_argument("--chunk", type=int, default=8, help="pairs per transfer chunk of --scatter")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -78,9 +133,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+        args.gpus = world   # an external launcher decides
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
     # SBM_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks (ranks then
@@ -121,6 +174,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     dL, dR = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
     dD = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+    scatter = args.scatter and world > 1
+    gL = gR = gD = None
+    xdev = dev if backend == "nccl" else torch.device("cpu")   # gloo moves host tensors
+    if scatter and rank == 0:
+        # the global batch (every rank's shard) resident on the root; pairs of rank r are generated as in the sharded run
+        parts = [synth.make_batch(r * B, uniq, W, H, nd) for r in range(world)]
+        gL = torch.from_numpy(np.concatenate([np.concatenate([pp[0]] * reps)[:B] for pp in parts])).to(xdev)
+        gR = torch.from_numpy(np.concatenate([np.concatenate([pp[1]] * reps)[:B] for pp in parts])).to(xdev)
+        gD = torch.empty((world * B, H, W), dtype=torch.int16, device=xdev)
 
     bm = pkg.StereoBM.create(nd, wsz, device=local_rank)
     bm.setPreFilterCap(31)
@@ -140,8 +202,22 @@ def main():
             torch.cuda.synchronize(dev)
 
     pl, pr, pd = dL.data_ptr(), dR.data_ptr(), dD.data_ptr()
+
+    def compute_chunk(l, r):      # per-rank engine call of the chunked scatter path (finished when it returns)
+        if l.is_cuda:
+            return bm.compute_device(l, r, sync=True)
+        return bm.compute_device(l.to(dev), r.to(dev), sync=True).cpu()
+
+    def step():
+        if scatter:
+            from u96_slam_amd import shard
+
+            shard.compute_sharded_chunked(compute_chunk, gL, gR, world * B, (H, W), chunk=args.chunk, src=0, device=xdev, out=gD)
+        else:
+            bm.launch_raw(B, pl, pr, W, H, pd)
+
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
-        bm.launch_raw(B, pl, pr, W, H, pd)
+        step()
     sync_all()
 
     bm.set_profiling(0 if args.no_profile else 2)  # stage events recorded on the engine's stream, no host sync inside the timed region
@@ -149,8 +225,8 @@ def main():
     t0 = time.perf_counter()
     gathered = None
     for _ in range(args.steps):
-        bm.launch_raw(B, pl, pr, W, H, pd)
-        if args.gather and dist is not None:
+        step()
+        if args.gather and dist is not None and not scatter:
             from u96_slam_amd import shard
 
             bm.synchronize()
@@ -236,7 +312,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H} gray, ndisp={nd}, {wsz}x{wsz} SAD, "
                        + ("texture 10 / uniqueness 10 / disp12MaxDiff 1 / speckle 50,32" if post else "texture 10 / uniqueness 10, no LR/speckle"),
-                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, " + ("disparity maps gathered on rank 0 each step" if (args.gather and world > 1) else "no data-path collective")},
+                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, " + (
+                           f"global batch on rank 0: chunked ({args.chunk} pairs) double-buffered point-to-point scatter + gather over {'RCCL' if backend == 'nccl' else backend} inside the timed region" if scatter
+                           else "disparity maps gathered on rank 0 each step" if (args.gather and world > 1) else "shards resident, no data-path collective")},
             "ms_per_pair": round(elapsed / (B * args.steps) * 1e3, 5),
             "pairs_per_s": round(total_pairs / elapsed, 1),
             "roofline": roofline, "roofline_prefilter": roofline_pf, "cpu_baseline": cpu,

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_pairs, q):
+def _worker(rank, world, port, n_pairs, q, chunk=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,7 +43,10 @@ def _worker(rank, world, port, n_pairs, q):
     if rank == 0:
         Ln, Rn = synth.make_batch(0, n_pairs, w, h, nd)
         L, R = torch.from_numpy(Ln), torch.from_numpy(Rn)
-    out = shard.compute_sharded(compute_fn, L, R, n_pairs, (h, w), src=0)
+    if chunk:
+        out = shard.compute_sharded_chunked(compute_fn, L, R, n_pairs, (h, w), chunk=chunk, src=0)
+    else:
+        out = shard.compute_sharded(compute_fn, L, R, n_pairs, (h, w), src=0)
     lo, hi = shard.shard_bounds(n_pairs, rank, world)
     if rank == 0:
         ref = sbm_oracle.compute_batch(p, Ln, Rn, threads=1)
@@ -55,12 +58,13 @@ def _worker(rank, world, port, n_pairs, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs", [4, 5, 1])
-def test_scatter_compute_gather_world2(n_pairs):
+@pytest.mark.parametrize("n_pairs,chunk", [(4, 0), (5, 0), (1, 0),     # whole blocks, point to point
+                                           (11, 2), (8, 8), (7, 3), (1, 2)])  # chunked + double-buffered, ragged last chunks
+def test_scatter_compute_gather_world2(n_pairs, chunk):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q, chunk)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
