@@ -81,17 +81,8 @@ extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NS
 // NDW disparities per wavefront, NWAVES wavefronts per workgroup covering NDW*NWAVES >= nd disparities of the SAME
 // 64 columns.  NWAVES > 1 keeps the register footprint of a wavefront at NDW/2 accumulators + NDW/2 sums (4 waves per
 // SIMD at NDW = 64) at the price of two workgroup barriers per row for the WTA merge through LDS.
-//
-// NSTRIP > 1 (halo sharing): the workgroup holds NSTRIP adjacent 64-column strips (NSTRIP * NWAVES wavefronts). The last
-// w - PW lanes of a strip have horizontal-window partners in the NEXT strip: instead of recomputing those columns (12 of
-// 64 lanes idle at w = 15, 18 at w = 21) the next strip's wavefront also writes the vertical sums of its first w - PW
-// lanes into the previous strip's exchange rows (an "inbox" right behind lane 63's entry), one extra workgroup barrier
-// per row makes them visible, and every lane of the strip produces an output. Only the last strip of the workgroup
-// keeps idle halo lanes. The exchange runs in two rounds that reuse the same rows, so the inbox exists twice: behind
-// the row for round 1 (entries addressed upwards) and in front of it for round 2, whose entries are addressed
-// downwards (lane l at 63 - l) -- both rounds keep one address register per lane and immediate offsets per partner.
-template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int NSTRIP>
-__global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64 && EXACT_ND) ? 4 : 1) sad_fast_kernel(FastArgs a) {
+template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND>
+__global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
   constexpr int NR = NDW / 2;           // packed pair registers
   constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
@@ -105,20 +96,8 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
   constexpr int XS = 64 + PW * (NTERM - 1);
   constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
 
-  constexpr int HALO = WSZ - PW;                 // lanes whose partners lie in the next strip
-  constexpr int NVT = 64 * (NSTRIP - 1) + NV;    // output columns of a workgroup
-  constexpr int RS = 64 + 2 * HALO;              // NSTRIP > 1: slots per exchange row (inbox 2 | 64 own | inbox 1)
-  constexpr int XROWS = XCH / 2;
-  static_assert(NSTRIP == 1 || NQ <= 2 * XCH, "halo sharing supports at most two exchange rounds");
-  // NSTRIP > 1 per-wavefront LDS (16-byte slots): exchange rows, texture row (2 parities), staging (only 63+4+64+1 are read)
-  constexpr int XT2 = (2 * (64 + HALO) * 4 + 15) / 16;
-  constexpr int ST2 = 63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1;
-  constexpr int WSLOT2 = XROWS * RS + XT2 + ST2;
-
   const int lane = threadIdx.x & 63;
-  const int wv_all = (NWAVES * NSTRIP) > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-  const int sidx = NSTRIP > 1 ? wv_all / NWAVES : 0;    // strip of this wavefront inside the workgroup
-  const int wv = NSTRIP > 1 ? wv_all % NWAVES : wv_all; // disparity group of this wavefront
+  const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int d0 = wv * NDW;                              // first buffer index of this wavefront
   // XCD-aware decode of the 1-D workgroup id: consecutive ids go round-robin over the 8 XCDs (each with its own
   // 4 MiB L2), so give XCD k the pairs k, k+8, ...: all strips and row segments of a pair then share one L2.
@@ -146,33 +125,23 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
     pair = p;
     strip = inner;
   }
-  const int c = strip * NVT + 64 * sidx + lane;         // this lane's column (relative to lofs): V covers c..c+2
+  const int c = strip * NV + lane;                      // this lane's column (relative to lofs): V covers c..c+2
   const int xc = c + W2;                                // centre column this lane produces
-  const bool produces = (sidx < NSTRIP - 1 || lane < NV) && xc >= a.xc0 && xc < a.xc1;
+  const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
   const int ys = a.segrow[segi];
   const int ye = a.segrow[segi + 1];
   const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;  // left bytes of this lane
   // right piece of the wavefront: window of buffer index d starts at rofs + c + d
-  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + strip * NVT + 64 * sidx + d0;
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + strip * NV + d0;
   // LDS carve-up (16-byte units): per wavefront one region of WSLOT slots that serves first as the staging area of a
   // row (apply) and then as the exchange area of the horizontal window -- never live together, and a wavefront's LDS
   // operations execute in order -- followed by the WTA merge area of the workgroup.
-  constexpr int WSLOT = NSTRIP > 1 ? WSLOT2 : (NSLOT > XSLOT ? NSLOT : XSLOT);
-  uint4* const wave_lds = fast_lds + wv_all * WSLOT;
-  // NSTRIP == 1: staging and exchange share the region. NSTRIP > 1: the neighbour writes into this wavefront's exchange
-  // rows while it may still be staging, so the staging area is separate.
-  uint4* const stage_lds = NSTRIP > 1 ? wave_lds + XROWS * RS + XT2 : wave_lds;
-  uint4* const xq = wave_lds;                                           // [XCH/2 quad pairs][XS or RS], 8 x u16 each
-  u32* const xt = reinterpret_cast<u32*>(xq + (NSTRIP > 1 ? XROWS * RS : (XCH / 2) * XS));  // texture column sums
-  constexpr int MP = NSTRIP > 1 ? 1 : 2;                                            // copies of the merge arrays
-  u32* const xkey0 = reinterpret_cast<u32*>(fast_lds + NWAVES * NSTRIP * WSLOT);   // [MP][NSTRIP][NWAVES][64]
-  uint2* const xacc0 = reinterpret_cast<uint2*>(xkey0 + MP * NSTRIP * NWAVES * 64); // [MP][NSTRIP][NWAVES][64]
-  u32* const xkey = xkey0 + sidx * NWAVES * 64;                          // this strip's [NWAVES][64] (parity stride below)
-  uint2* const xacc = xacc0 + sidx * NWAVES * 64;                        // (deficit acc, nn | pp<<16)
-  constexpr int PSTR = NSTRIP * NWAVES * 64;                             // parity stride of xkey / xacc
-  // the previous strip's exchange rows / texture row (same disparity group): the inbox this wavefront fills
-  uint4* const nb_xq = wave_lds - NWAVES * WSLOT;
-  u32* const nb_xt = reinterpret_cast<u32*>(nb_xq + XROWS * RS);
+  constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
+  uint4* const stage_lds = fast_lds + wv * WSLOT;
+  uint4* const xq = stage_lds;                                          // [XCH/2 quad pairs][XS lanes], 8 x u16 each
+  u32* const xt = reinterpret_cast<u32*>(xq + (XCH / 2) * XS);          // [XS] texture column sums
+  u32* const xkey = reinterpret_cast<u32*>(fast_lds + NWAVES * WSLOT);  // [2][NWAVES][64]
+  uint2* const xacc = reinterpret_cast<uint2*>(xkey + 2 * NWAVES * 64); // [2][NWAVES][64]  (deficit acc, nn | pp<<16)
   const u32 capw = (u32)a.capb * 0x01010101u;
 
   // packed 4 x u16 per quad (low dword = indices 4q,4q+1, high dword = 4q+2,4q+3).  Two arrays in ping-pong:
@@ -200,8 +169,7 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
   // mode 0: VB = VA + row (enter)   mode 1: VA = VB - row (leave)   mode 2: VA = VB + row (second half of a prime pair)
   auto apply = [&](const RowRegs& g, const int mode) {
 #pragma unroll
-    for (int it = 0; it < NIT; it++)
-      if (NSTRIP == 1 || it * 64 + 63 < ST2 || it * 64 + lane < ST2) stage_lds[it * 64 + lane] = g.r[it];
+    for (int it = 0; it < NIT; it++) stage_lds[it * 64 + lane] = g.r[it];
     constexpr u32 PMASK = PW == 3 ? 0x00ffffffu : 0x000000ffu;
     const u32 pat = g.l & PMASK;  // remaining bytes = 0 -> masked by mqsad
     const u32 tv = __builtin_amdgcn_sad_u8(pat | (capw & ~PMASK), capw, 0u);
@@ -259,43 +227,8 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
   }
   // g now holds row ys+W2
   const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
-  // NSTRIP > 1: round-1 entries of a row, both inboxes of the previous strip and the texture column, published as soon
-  // as VB of that row exists -- i.e. BEFORE the previous row's second merge barrier, which then also makes the inboxes
-  // visible: halo sharing costs no barrier of its own. (Safe: the exchange entries of the previous row were consumed
-  // before its first merge barrier; the texture row alternates by row parity because the finishing wavefront reads it late.)
-  auto publish = [&](int yrow) {
-    constexpr int XTS = 64 + HALO;
-    const int pr_ = yrow & 1;
-    xt[pr_ * XTS + lane] = Vt;
-#pragma unroll
-    for (int qq = 0; qq < XCH; qq += 2) {
-      const uint2 v0 = __builtin_bit_cast(uint2, VB[qq]), v1 = __builtin_bit_cast(uint2, VB[qq + 1]);
-      xq[(qq / 2) * RS + HALO + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
-    }
-    if (sidx > 0 && lane < HALO) {
-      nb_xt[pr_ * XTS + 64 + lane] = Vt;
-#pragma unroll
-      for (int qq = 0; qq < XCH; qq += 2) {
-        const uint2 v0 = __builtin_bit_cast(uint2, VB[qq]), v1 = __builtin_bit_cast(uint2, VB[qq + 1]);
-        nb_xq[(qq / 2) * RS + HALO + 64 + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
-      }
-      if constexpr (NQ > XCH) {
-#pragma unroll
-        for (int qq = 0; qq < XCH; qq += 2) {
-          const uint2 v0 = __builtin_bit_cast(uint2, VB[XCH + qq]), v1 = __builtin_bit_cast(uint2, VB[XCH + qq + 1]);
-          nb_xq[(qq / 2) * RS + HALO - 1 - lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        }
-      }
-    }
-  };
-  if constexpr (NSTRIP > 1) {
-    apply(g, 0);
-    publish(ys);
-    if (ys + 1 < ye) g = fetch(ys + 1 + W2);
-    __syncthreads();
-  }
   for (int y = ys; y < ye; y++) {
-    if constexpr (NSTRIP == 1) apply(g, 0);
+    apply(g, 0);
 
     // ---- horizontal window across lanes ------------------------------------------------------------------
     // S(c + w/2) = sum_k V(c + 3k): every lane publishes its V quads to LDS ([quad][lane], 8-byte entries: both
@@ -305,87 +238,35 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
     // Lanes >= NV read beyond lane 63 (unwritten halo entries): their sums are garbage and never stored.
     u32 S[NR];
     const int par = y & 1;
-    if constexpr (NSTRIP == 1) {
-      xt[lane] = Vt;
+    xt[lane] = Vt;
 #pragma unroll
-      for (int q0 = 0; q0 < NQ; q0 += XCH) {
-        // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
-#pragma unroll
-        for (int qq = 0; qq < XCH; qq += 2) {
-          const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
-          xq[(qq / 2) * XS + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int qq = 0; qq < XCH; qq += 2) {
-          const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
-          u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
-#pragma unroll
-          for (int k = 1; k < NTERM; k++) {
-            const uint4 r = xq[(qq / 2) * XS + lane + PW * k];
-            s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
-            s1 += r.y;
-            s2 += r.z;
-            s3 += r.w;
-          }
-          S[2 * (q0 + qq)] = s0;
-          S[2 * (q0 + qq) + 1] = s1;
-          S[2 * (q0 + qq) + 2] = s2;
-          S[2 * (q0 + qq) + 3] = s3;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    } else {
-      // ---- halo sharing: own entries at [HALO, HALO+64) of every row, the next strip's first HALO lanes behind them
-      // (round 1) and, mirrored, in front of them (round 2); published by publish() one barrier ago
+    for (int q0 = 0; q0 < NQ; q0 += XCH) {
+      // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
 #pragma unroll
       for (int qq = 0; qq < XCH; qq += 2) {
-        const uint2 v0 = __builtin_bit_cast(uint2, VB[qq]), v1 = __builtin_bit_cast(uint2, VB[qq + 1]);
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
+        xq[(qq / 2) * XS + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int qq = 0; qq < XCH; qq += 2) {
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
         u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
 #pragma unroll
         for (int k = 1; k < NTERM; k++) {
-          const uint4 r = xq[(qq / 2) * RS + HALO + lane + PW * k];
-          s0 += r.x;
+          const uint4 r = xq[(qq / 2) * XS + lane + PW * k];
+          s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
           s1 += r.y;
           s2 += r.z;
           s3 += r.w;
         }
-        S[2 * qq] = s0;
-        S[2 * qq + 1] = s1;
-        S[2 * qq + 2] = s2;
-        S[2 * qq + 3] = s3;
+        S[2 * (q0 + qq)] = s0;
+        S[2 * (q0 + qq) + 1] = s1;
+        S[2 * (q0 + qq) + 2] = s2;
+        S[2 * (q0 + qq) + 3] = s3;
       }
-      if constexpr (NQ > XCH) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int qq = 0; qq < XCH; qq += 2) {
-          const uint2 v0 = __builtin_bit_cast(uint2, VB[XCH + qq]), v1 = __builtin_bit_cast(uint2, VB[XCH + qq + 1]);
-          xq[(qq / 2) * RS + HALO + 63 - lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int qq = 0; qq < XCH; qq += 2) {
-          const uint2 v0 = __builtin_bit_cast(uint2, VB[XCH + qq]), v1 = __builtin_bit_cast(uint2, VB[XCH + qq + 1]);
-          u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
-#pragma unroll
-          for (int k = 1; k < NTERM; k++) {
-            const uint4 r = xq[(qq / 2) * RS + HALO + 63 - lane - PW * k];
-            s0 += r.x;
-            s1 += r.y;
-            s2 += r.z;
-            s3 += r.w;
-          }
-          S[2 * (XCH + qq)] = s0;
-          S[2 * (XCH + qq) + 1] = s1;
-          S[2 * (XCH + qq) + 2] = s2;
-          S[2 * (XCH + qq) + 3] = s3;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      // without WTA-merge barriers nothing else keeps the next row's inbox writes behind this row's reads
-      if constexpr (NWAVES == 1) __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
     if constexpr (!EXACT_ND) {
 #pragma unroll
@@ -410,9 +291,7 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
       best = min(best, bg);
     }
     best += (u32)d0;
-    // (NSTRIP > 1: three barriers per row already separate a row's merge traffic from the next row's, so one copy of
-    // the merge arrays is enough; the two-barrier NSTRIP == 1 kernel alternates between two by row parity)
-    const int mpar = NSTRIP > 1 ? 0 : par * PSTR;
+    const int mpar = par * NWAVES * 64;   // the merge arrays alternate by row parity
     if constexpr (NWAVES > 1) {
       xkey[mpar + wv * 64 + lane] = best;
       __syncthreads();
@@ -432,7 +311,7 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
       // reach 65536 (host check, uniq_plain) the partial sums are plain 32-bit adds of the packed halves -- no carry
       // can cross -- and only the final combine saturates. Saturating adds give min(65535, sum) in any grouping.
       u32 ac[4] = {0u, 0u, 0u, 0u};
-      if (a.uniq_plain) {
+      if (NR <= 32 && a.uniq_plain) {
 #pragma unroll
         for (int j = 0; j < NR; j++) ac[j & 3] += pk_sub_sat(T2, S[j]);
       } else {
@@ -474,21 +353,9 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
     int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
     u32 acc_lo = acc & 0xffffu, acc_hi = acc >> 16;
     bool mine = true;  // does this wavefront finalise this row?
-    if constexpr (NWAVES > 1) xacc[mpar + wv * 64 + lane] = make_uint2(acc, X[0]);
-    // NSTRIP > 1: slide the window to row y+1 and publish it before the barrier (see publish()). With cooperating
-    // wavefronts that is here, ahead of the merge barrier; a lone wavefront finishes its row first (it would otherwise
-    // carry the whole finishing state across the two row updates) and synchronises at the end of the iteration.
-    auto advance = [&]() {
-      if (y + 1 < ye) {
-        apply(lv, 1);
-        apply(g, 0);
-        publish(y + 1);
-        if (y + 2 < ye) g = fetch(y + 2 + W2);
-      }
-    };
-    if constexpr (NSTRIP > 1 && NWAVES > 1) advance();
-    if constexpr (NWAVES > 1) __syncthreads();
     if constexpr (NWAVES > 1) {
+      xacc[mpar + wv * 64 + lane] = make_uint2(acc, X[0]);
+      __syncthreads();
       mine = (y % NWAVES) == wv;
       if (mine) {
         acc_lo = acc_hi = 0;
@@ -504,9 +371,9 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
     }
 
     if (mine) {
-      int tsum = NSTRIP > 1 ? (int)xt[par * (64 + HALO) + lane] : (int)Vt;   // (NSTRIP > 1: Vt already belongs to row y+1)
+      int tsum = (int)Vt;
 #pragma unroll
-      for (int k = 1; k < NTERM; k++) tsum += (int)xt[(NSTRIP > 1 ? par * (64 + HALO) : 0) + lane + PW * k];
+      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + PW * k];
       bool ok = tsum >= a.tex;
       // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
       if (a.uniq > 0) {
@@ -538,14 +405,9 @@ __global__ void __launch_bounds__(64 * NWAVES * NSTRIP, (NSTRIP > 1 && NDW == 64
       }
     }
 
-    if constexpr (NSTRIP == 1) {
-      if (y + 1 < ye) {
-        g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
-        apply(lv, 1);
-      }
-    } else if constexpr (NWAVES == 1) {
-      advance();
-      __syncthreads();
+    if (y + 1 < ye) {
+      g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
+      apply(lv, 1);
     }
   }
 }
@@ -562,41 +424,38 @@ bool sad_fast_supported(const Geom& g) {
   return true;
 }
 
-template <int NDW, int NWAVES, int NTERM, int PW, int NSTRIP>
+template <int NDW, int NWAVES, int NTERM, int PW>
 static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
   constexpr int NCH = (NDW / 4 + 15) / 16;
   constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
   constexpr int NQ = NDW / 4, XCH = NQ < 8 ? NQ : 8;
   constexpr int XS = 64 + PW * (NTERM - 1);
   constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
-  constexpr int HALO = PW * (NTERM - 1), RS = 64 + 2 * HALO;
-  constexpr int WSLOT2 = (XCH / 2) * RS + (2 * (64 + HALO) * 4 + 15) / 16 + (63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1);
-  constexpr int WSLOT = NSTRIP > 1 ? WSLOT2 : (NSLOT > XSLOT ? NSLOT : XSLOT);
-  constexpr int MP = NSTRIP > 1 ? 1 : 2;
-  const size_t lds = (size_t)NWAVES * NSTRIP * WSLOT * 16 + (NWAVES > 1 ? (size_t)MP * NSTRIP * NWAVES * 64 * (4 + 8) : 0);
+  constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
+  const size_t lds = (size_t)NWAVES * WSLOT * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   if (a.nd == NDW * NWAVES)
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true, NSTRIP>), grid, dim3(64 * NWAVES * NSTRIP), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true>), grid, dim3(64 * NWAVES), lds, s, a);
   else
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, false, NSTRIP>), grid, dim3(64 * NWAVES * NSTRIP), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, false>), grid, dim3(64 * NWAVES), lds, s, a);
   return hipGetLastError();
 }
 
 // mode 0 (default): 64 disparities per wavefront, nd/64 cooperating wavefronts.  mode 1: one wavefront holds all
 // (<= 128) disparities -- kept for A/B measurements (env SBM_FAST_MODE=1).
-template <int NTERM, int PW, int NSTRIP>
+template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, bool split, hipStream_t s) {
-  if (a.nd <= 32) return launch_t<32, 1, NTERM, PW, NSTRIP>(a, grid, s);
-  if (a.nd == 48) return launch_t<32, 2, NTERM, PW, NSTRIP>(a, grid, s);   // the masked single-wavefront variant needs 174 VGPRs
+  if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, grid, s);
+  if (a.nd == 48) return launch_t<32, 2, NTERM, PW>(a, grid, s);   // the masked single-wavefront variant needs 174 VGPRs
   // one-pair calls: too few workgroups to fill the chip, so split the disparities over two wavefronts (half the serial work
   // per row; SBM_FAST_SPLIT=0 disables)
-  if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW, NSTRIP>(a, grid, s);
-  if (a.nd <= 64) return launch_t<64, 1, NTERM, PW, NSTRIP>(a, grid, s);
-  if constexpr (PW == 3 && NSTRIP == 1) {
-    if (a.nd <= 128 && mode == 1) return launch_t<128, 1, NTERM, PW, 1>(a, grid, s);
+  if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW>(a, grid, s);
+  if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, grid, s);
+  if constexpr (PW == 3) {
+    if (a.nd <= 128 && mode == 1) return launch_t<128, 1, NTERM, PW>(a, grid, s);
   }
-  if (a.nd <= 128) return launch_t<64, 2, NTERM, PW, NSTRIP>(a, grid, s);
-  if (a.nd <= 192) return launch_t<64, 3, NTERM, PW, NSTRIP>(a, grid, s);
-  return launch_t<64, 4, NTERM, PW, NSTRIP>(a, grid, s);
+  if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, grid, s);
+  if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, grid, s);
+  return launch_t<64, 4, NTERM, PW>(a, grid, s);
 }
 
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
@@ -614,22 +473,16 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   a.xc0 = g.w2; a.xc1 = xhi - g.w2 + 1;
   const int pw = g.wsz % 3 == 0 ? 3 : 1;
   const int nv = 64 - (g.wsz - pw);
-  // halo sharing (two strips per workgroup): built for the windows that are multiples of 3; pays when there are at
-  // least two strips to pair (SBM_FAST_NSTRIP=1 disables)
-  static const int nstrip_env = [] { const char* e = getenv("SBM_FAST_NSTRIP"); return e ? atoi(e) : 1; }();
-  const int ncols = a.xc1 - a.xc0;
-  int nstrip = (pw == 3 && nstrip_env >= 2 && mode != 1 && ncols > nv) ? 2 : 1;
-  const int nvt = 64 * (nstrip - 1) + nv;
-  const int strips = (ncols + nvt - 1) / nvt;
+  const int strips = (a.xc1 - a.xc0 + nv - 1) / nv;
   const int rows = g.row1 - g.row0;
   // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
   // segment at ~1/3 of a full row's cost) below ~10 %
   int nseg = 1;
   static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 9000L; }();
-  while ((long)strips * nstrip * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
+  while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
   // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
   // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
-  while ((long)strips * nstrip * nseg * g.n < 1024 && rows / (nseg + 1) >= g.wsz && nseg < 32) nseg++;
+  while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= g.wsz && nseg < 32) nseg++;
   static const int nseg_env = [] { const char* e = getenv("SBM_FAST_NSEG"); return e ? atoi(e) : 0; }();
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
   // taper: the last third of the rows is cut into segments of 2/3, 1/2, 1/3 ... of the regular length
@@ -660,30 +513,21 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   }
   dim3 grid((unsigned)strips * nseg * g.n);
   static const int split_env = [] { const char* e = getenv("SBM_FAST_SPLIT"); return e ? atoi(e) : 1; }();
-  const bool split = grid.x * (unsigned)nstrip < 1024 && split_env;
+  const bool split = grid.x < 1024 && split_env;
   hipError_t e;
-  if (nstrip == 2) {
-    switch (g.wsz) {
-      case 9: e = launch_nd<3, 3, 2>(a, grid, mode, split, s); break;
-      case 15: e = launch_nd<5, 3, 2>(a, grid, mode, split, s); break;
-      case 21: e = launch_nd<7, 3, 2>(a, grid, mode, split, s); break;
-      default: e = launch_nd<9, 3, 2>(a, grid, mode, split, s); break;
-    }
-  } else {
-    switch (g.wsz) {
-      case 9: e = launch_nd<3, 3, 1>(a, grid, mode, split, s); break;
-      case 15: e = launch_nd<5, 3, 1>(a, grid, mode, split, s); break;
-      case 21: e = launch_nd<7, 3, 1>(a, grid, mode, split, s); break;
-      case 27: e = launch_nd<9, 3, 1>(a, grid, mode, split, s); break;
-      case 5: e = launch_nd<5, 1, 1>(a, grid, mode, split, s); break;
-      case 7: e = launch_nd<7, 1, 1>(a, grid, mode, split, s); break;
-      case 11: e = launch_nd<11, 1, 1>(a, grid, mode, split, s); break;
-      case 13: e = launch_nd<13, 1, 1>(a, grid, mode, split, s); break;
-      case 17: e = launch_nd<17, 1, 1>(a, grid, mode, split, s); break;
-      case 19: e = launch_nd<19, 1, 1>(a, grid, mode, split, s); break;
-      case 23: e = launch_nd<23, 1, 1>(a, grid, mode, split, s); break;
-      default: e = launch_nd<25, 1, 1>(a, grid, mode, split, s); break;
-    }
+  switch (g.wsz) {
+    case 9: e = launch_nd<3, 3>(a, grid, mode, split, s); break;
+    case 15: e = launch_nd<5, 3>(a, grid, mode, split, s); break;
+    case 21: e = launch_nd<7, 3>(a, grid, mode, split, s); break;
+    case 27: e = launch_nd<9, 3>(a, grid, mode, split, s); break;
+    case 5: e = launch_nd<5, 1>(a, grid, mode, split, s); break;
+    case 7: e = launch_nd<7, 1>(a, grid, mode, split, s); break;
+    case 11: e = launch_nd<11, 1>(a, grid, mode, split, s); break;
+    case 13: e = launch_nd<13, 1>(a, grid, mode, split, s); break;
+    case 17: e = launch_nd<17, 1>(a, grid, mode, split, s); break;
+    case 19: e = launch_nd<19, 1>(a, grid, mode, split, s); break;
+    case 23: e = launch_nd<23, 1>(a, grid, mode, split, s); break;
+    default: e = launch_nd<25, 1>(a, grid, mode, split, s); break;
   }
   *xa = a.xc0; *xb = a.xc1;
   return e;
