@@ -212,6 +212,43 @@ int sbm_rect_remap_device(sbm_handle* h, int n, const void* d_src, const void* d
 int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int height, int flavour, int cap,
                          void* d_dst, int sync);
 
+/* ---- the reference's own matcher: FPGA flavour (SURVEY.md 8f rank 3 + 8a row a8) -------------------------------------
+ * Bit-level restatement of the block matcher the reference runs in programmable logic (src/dvp/rtl/bm*.v, fed by
+ * xsbl2.v), for consumers of DEPTH_METHOD_FPGA_BM (src/slam/src/core/FPGA.cpp:270-279): 6-bit x-Sobel inputs, 10-bit
+ * saturating column sums, 32-disparity phases, tournament minimum, divider-based sub-pixel fraction, optional min1/min2
+ * ratio filter, int16 s11.4 output with -1 (0xFFFF) for "no disparity" and for the never-computed borders
+ * (hwsz rows top and bottom, ndisp + hwsz + 1 columns left, hwsz columns right). It differs from cv::StereoBM in every
+ * stage; no texture threshold, LR check or speckle filter exists in this flavour.
+ * Parameters are the fields of the BM register block, struct FPGA_REG_BM (src/StereoBM/src/fpga.h:154-169) as decoded by
+ * src/dvp/rtl/bm.v:172-193; the firmware programs ImageSize = 480 << 16 | 640, BmSetting = 0x00150040 (window 21,
+ * 64 disparities) and leaves UniFiltCtrl at 0 (src/StereoBM/src/fpga.c:150-160). */
+typedef struct sbm_fpga_params {
+  int32_t width;            /* ImageSize [9:0]    */
+  int32_t height;           /* ImageSize [24:16]  */
+  int32_t block_size;       /* BmSetting [20:16]  wsz: odd, 3..31 */
+  int32_t num_disparities;  /* BmSetting [8:0]    ndisp: multiple of 32, 32..256 (whole disparity phases) */
+  int32_t uni_enable;       /* UniFiltCtrl [31]   */
+  int32_t uni_mode;         /* UniFiltCtrl [16]   0: rejected pixels read 0xFFFF, 1: they read disparity 255 + 255/256 */
+  int32_t uni_threshold;    /* UniFiltCtrl [9:0]  reject when min1/min2 (u0.10) > threshold */
+} sbm_fpga_params;
+
+/* Register words -> parameters, exactly the bit fields of bm.v:172-193 (no validation). */
+int sbm_fpga_params_from_regs(uint32_t image_size, uint32_t bm_setting, uint32_t uni_filt_ctrl, sbm_fpga_params* out);
+/* Read-back value of SAD_Size [1724h] = sad_hgt << 16 | sad_wdt (bm.v:208,249-255). */
+uint32_t sbm_fpga_sad_size_reg(const sbm_fpga_params* p);
+/* Limits of the RTL as status codes: field widths (width <= 1023, height <= 511), odd window 3..31, ndisp a positive
+ * multiple of 32 up to 256, at least one output pixel; SBM_ERR_UNSUPPORTED for (ndisp + hwsz + 1) % 32 == 0, where the
+ * RTL's output sequencer (bm_obuf2.v:239) never leaves its fill state. */
+int sbm_fpga_params_validate(const sbm_fpga_params* p);
+/* The matcher on n dense pairs of x-Sobel planes (what data/ref_xsbl_{l,r} are: xsbl2.v output, 0..63) resident in
+ * device memory; d_disp = n*height*width int16. Asynchronous on the handle's stream unless sync != 0. */
+int sbm_fpga_bm_device(sbm_handle* h, int n, const void* d_xsbl_l, const void* d_xsbl_r, const sbm_fpga_params* p,
+                       void* d_disp, int sync);
+/* xsbl2.v prefilter (SBM_PREFILTER_FLAVOUR_RTL) of n dense rectified pairs followed by the matcher: the whole PL
+ * pipeline behind Fpga::receiveDepthMap. */
+int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, const sbm_fpga_params* p,
+                            void* d_disp, int sync);
+
 /* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours (record an event on it
  * after sbm_compute_device(..., sync = 0)) or ours behind theirs (hipStreamWaitEvent on it before the call). Every entry
  * point selects the handle's device for the duration of the call and restores the caller's current device on return. */

@@ -1,0 +1,79 @@
+// The reference's call site (src/slam/src/core/main.cpp:197-217) with the one-line type swap of INTEGRATION.md:
+// a matcher is created INSIDE the frame loop (main.cpp:201), configured with the 11 setters (main.cpp:202-212) and
+// asked for one disparity map (main.cpp:215). Frames come from raw 8-bit files instead of cv::imread so that the
+// program builds without OpenCV; with OpenCV headers present the cv::InputArray overload is exercised as well
+// (compile with -DSBM_TEST_WITH_OPENCV).
+//
+//   callsite_main <width> <height> <nframes> <left.raw> <right.raw> <disp_out.raw>
+//
+// left/right hold nframes dense frames; disp_out receives nframes dense int16 maps. Exit code 0 on success.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "sbm_stereobm.hpp"
+
+static bool read_all(const char* path, std::vector<uint8_t>& buf) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return false;
+  const size_t got = std::fread(buf.data(), 1, buf.size(), f);
+  std::fclose(f);
+  return got == buf.size();
+}
+
+int main(int argc, char** argv) {
+  if (argc != 7) return 2;
+  const int W = std::atoi(argv[1]), H = std::atoi(argv[2]), N = std::atoi(argv[3]);
+  const size_t npix = (size_t)W * H;
+  std::vector<uint8_t> left(npix * N), right(npix * N);
+  std::vector<int16_t> disp(npix * N);
+  if (!read_all(argv[4], left) || !read_all(argv[5], right)) return 3;
+  try {
+    for (int i = 0; i < N; i++) {                                     // while(1) of main.cpp:149
+      // --- main.cpp:198-212, cv::StereoBM -> sbm::StereoBM ---------------------------------------------------------
+      auto bm = sbm::StereoBM::create(16, 9);
+      bm->setROI1(0, 0, 0, 0);                                       // cv::Rect roi1, roi2 are empty (main.cpp:199-203)
+      bm->setROI2(0, 0, 0, 0);
+      bm->setPreFilterCap(31);
+      bm->setBlockSize(21);
+      bm->setMinDisparity(0);
+      bm->setNumDisparities(64);
+      bm->setTextureThreshold(10);
+      bm->setUniquenessRatio(10);
+      bm->setSpeckleWindowSize(50);
+      bm->setSpeckleRange(32);
+      bm->setDisp12MaxDiff(1);
+      // --- main.cpp:215 ---------------------------------------------------------------------------------------------
+#ifdef SBM_TEST_WITH_OPENCV
+      cv::Mat l(H, W, CV_8UC1, left.data() + i * npix), r(H, W, CV_8UC1, right.data() + i * npix), d;
+      bm->compute(l, r, d);
+      if (d.type() != CV_16SC1 || d.rows != H || d.cols != W) return 5;
+      for (int y = 0; y < H; y++) std::copy(d.ptr<int16_t>(y), d.ptr<int16_t>(y) + W, disp.data() + i * npix + (size_t)y * W);
+#else
+      bm->compute(left.data() + i * npix, (size_t)W, right.data() + i * npix, (size_t)W, W, H, disp.data() + i * npix,
+                  (size_t)W * sizeof(int16_t));
+#endif
+    }
+    // parameter violations surface from compute(), as cv::StereoBM's CV_Error does (numDisparities % 16 != 0)
+    auto bad = sbm::StereoBM::create(20, 9);
+    bool threw = false;
+    try {
+      bad->compute(left.data(), (size_t)W, right.data(), (size_t)W, W, H, disp.data(), (size_t)W * 2);
+    } catch (const sbm::Error& e) {
+      threw = e.code == SBM_ERR_NUM_DISPARITIES;
+    }
+#ifdef SBM_HAVE_OPENCV
+    catch (const cv::Exception&) { threw = true; }
+#endif
+    if (!threw) return 6;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "callsite_main: %s\n", e.what());
+    return 4;
+  }
+  FILE* f = std::fopen(argv[6], "wb");
+  if (!f) return 3;
+  std::fwrite(disp.data(), sizeof(int16_t), disp.size(), f);
+  std::fclose(f);
+  std::printf("ok %d frames %dx%d\n", N, W, H);
+  return 0;
+}

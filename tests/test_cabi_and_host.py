@@ -110,3 +110,19 @@ int main() {
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout, r.stderr)
+
+
+def test_fpga_register_decode_matches_oracle_and_firmware(pkg, oracle):
+    """Host side of the FPGA flavour (no GPU needed): sbm_fpga_params_from_regs / _validate / _sad_size_reg against the
+    oracle's restatement of bm.v:172-193,208,249-255 and against the words the firmware writes (fpga.c:155,158)."""
+    p = pkg.fpga_params_from_regs((480 << 16) + 640, 0x00150040, 0)
+    assert (p.width, p.height, p.block_size, p.num_disparities, p.uni_enable, p.uni_mode, p.uni_threshold) == (640, 480, 21, 64, 0, 0, 0)
+    # bm.v:235-245 documents sad_wdt 491 / sad_hgt 460 for ndisp 128; with the firmware's ndisp 64: 640-64-1-20 = 555
+    assert pkg.fpga_sad_size_reg(p) == (460 << 16) | 555
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        regs = [int(v) for v in rng.integers(0, 2**32, 3, dtype=np.uint64)]
+        q = pkg.fpga_params_from_regs(*regs)
+        o = oracle.fpga_regs_decode(*regs)
+        assert (q.width, q.height, q.block_size, q.num_disparities, q.uni_enable, q.uni_mode, q.uni_threshold) == tuple(o.values())
+        assert pkg.fpga_validate(q) == oracle.fpga_check(q.width, q.height, q.block_size, q.num_disparities)

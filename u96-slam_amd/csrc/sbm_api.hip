@@ -35,6 +35,11 @@ struct sbm_handle {
   int16_t* disp_pre;
   int32_t *cost, *labels, *counts;
   uint16_t* vsum;      // column sums of PREFILTER_NORMALIZED_RESPONSE (2 * cap_n * W * H), allocated on first use
+  // FPGA-flavour matcher scratch (allocated on first use, sized for fp_n pairs of fp_W x fp_H)
+  int fp_n, fp_W, fp_H;
+  uint8_t *fp_pad_l, *fp_pad_r, *fp_xs_l, *fp_xs_r;
+  void* fp_rec;
+  int* fp_flag;
   // staging for the host-buffer entry points
   int st_n, st_W, st_H;
   uint8_t *st_l, *st_r;
@@ -143,6 +148,12 @@ static void free_scratch(sbm_handle* h) {
   h->cap_n = h->cap_W = h->cap_H = h->cap_pitch = 0;
 }
 
+static void free_fpga(sbm_handle* h) {
+  hipFree(h->fp_pad_l); hipFree(h->fp_pad_r); hipFree(h->fp_xs_l); hipFree(h->fp_xs_r); hipFree(h->fp_rec); hipFree(h->fp_flag);
+  h->fp_pad_l = h->fp_pad_r = h->fp_xs_l = h->fp_xs_r = nullptr; h->fp_rec = nullptr; h->fp_flag = nullptr;
+  h->fp_n = h->fp_W = h->fp_H = 0;
+}
+
 static void free_staging(sbm_handle* h) {
   hipFree(h->st_l); hipFree(h->st_r); hipFree(h->st_d);
   if (h->pin) hipHostFree(h->pin);
@@ -166,6 +177,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   if (h->labels) b += npix * 8;
   if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
+  b += (size_t)h->fp_n * h->fp_W * h->fp_H * 12 + (size_t)2 * h->fp_n * (h->fp_W + 191) * h->fp_H;
   return b;
 }
 
@@ -254,6 +266,7 @@ void sbm_destroy(sbm_handle* h) {
       if (scratch_bytes(h) > kPoolScratch) {
         free_scratch(h);
         free_staging(h);
+        free_fpga(h);
       }
       g_pool[g_pool_n++] = h;
       return;
@@ -270,6 +283,7 @@ static void destroy_now(sbm_handle* h) {
   sync_all_streams(h);
   free_scratch(h);
   free_staging(h);
+  free_fpga(h);
   for (int r = 0; r < sbm_handle::kRing; r++)
     for (int i = 0; i < sbm_handle::kMarks; i++)
       if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
@@ -582,6 +596,95 @@ int sbm_prefilter_device(sbm_handle* h, int n, const void* d_src, int width, int
   HIPCHK(h, dscope.enter());
   HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_src, (uint8_t*)d_dst, n, width, height,
                                    flavour == SBM_PREFILTER_FLAVOUR_RTL, cap, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+// ---- FPGA flavour: register decode (bm.v:172-193), limits, entry points -----------------------------------------------------
+int sbm_fpga_params_from_regs(uint32_t image_size, uint32_t bm_setting, uint32_t uni_filt_ctrl, sbm_fpga_params* out) {
+  if (!out) return SBM_ERR_NULL;
+  out->width = (int32_t)(image_size & 0x3ffu);
+  out->height = (int32_t)((image_size >> 16) & 0x1ffu);
+  out->block_size = (int32_t)((bm_setting >> 16) & 0x1fu);
+  out->num_disparities = (int32_t)(bm_setting & 0x1ffu);
+  out->uni_enable = (int32_t)((uni_filt_ctrl >> 31) & 1u);
+  out->uni_mode = (int32_t)((uni_filt_ctrl >> 16) & 1u);
+  out->uni_threshold = (int32_t)(uni_filt_ctrl & 0x3ffu);
+  return SBM_OK;
+}
+
+uint32_t sbm_fpga_sad_size_reg(const sbm_fpga_params* p) {
+  if (!p) return 0;
+  const uint32_t hwsz = ((uint32_t)p->block_size >> 1) & 0xfu;
+  const uint32_t hsad_wdt = ((uint32_t)p->width - (uint32_t)p->num_disparities - 1u) & 0x3ffu;   // bm.v:249
+  const uint32_t sad_wdt = (hsad_wdt - 2u * hwsz) & 0x3ffu;                                        // bm.v:252
+  const uint32_t sad_hgt = ((uint32_t)p->height - 2u * hwsz) & 0x1ffu;                             // bm.v:255
+  return (sad_hgt << 16) | sad_wdt;
+}
+
+int sbm_fpga_params_validate(const sbm_fpga_params* p) {
+  if (!p) return SBM_ERR_NULL;
+  if (p->width <= 0 || p->height <= 0 || p->width > 1023 || p->height > 511) return SBM_ERR_SIZE;
+  if (p->block_size < 3 || p->block_size > 31 || (p->block_size & 1) == 0) return SBM_ERR_BLOCK_SIZE;
+  if (p->num_disparities < 32 || p->num_disparities > 256 || (p->num_disparities & 31)) return SBM_ERR_NUM_DISPARITIES;
+  const int hwsz = p->block_size >> 1;
+  if (p->width - p->num_disparities - 1 - 2 * hwsz < 1 || p->height - 2 * hwsz < 1) return SBM_ERR_SIZE;
+  if (((p->num_disparities + hwsz + 1) & 31) == 0) return SBM_ERR_UNSUPPORTED;
+  return SBM_OK;
+}
+
+static int ensure_fpga(sbm_handle* h, int n, int W, int H, bool need_xs) {
+  const bool fits = n <= h->fp_n && W == h->fp_W && H == h->fp_H && h->fp_pad_l;
+  if (!fits) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    free_fpga(h);
+    const size_t padb = (size_t)n * fpga_pitch(W) * H + 64, npix = (size_t)n * W * H;
+    HIPCHK(h, hipMalloc((void**)&h->fp_pad_l, padb));
+    HIPCHK(h, hipMalloc((void**)&h->fp_pad_r, padb));
+    HIPCHK(h, hipMalloc(&h->fp_rec, npix * 8));
+    HIPCHK(h, hipMalloc((void**)&h->fp_flag, (size_t)n * sizeof(int)));
+    h->fp_n = n; h->fp_W = W; h->fp_H = H;
+  }
+  if (need_xs && !h->fp_xs_l) {
+    const size_t npix = (size_t)h->fp_n * W * H;
+    HIPCHK(h, hipMalloc((void**)&h->fp_xs_l, npix + 64));
+    HIPCHK(h, hipMalloc((void**)&h->fp_xs_r, npix + 64));
+  }
+  return SBM_OK;
+}
+
+int sbm_fpga_bm_device(sbm_handle* h, int n, const void* d_xsbl_l, const void* d_xsbl_r, const sbm_fpga_params* p,
+                       void* d_disp, int sync) {
+  if (!h || !d_xsbl_l || !d_xsbl_r || !p || !d_disp) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  int st = sbm_fpga_params_validate(p);
+  if (st != SBM_OK) return st;
+  if (n > 65535) return SBM_ERR_UNSUPPORTED;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  st = ensure_fpga(h, n, p->width, p->height, false);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, launch_fpga_bm((const uint8_t*)d_xsbl_l, (const uint8_t*)d_xsbl_r, h->fp_pad_l, h->fp_pad_r, h->fp_rec, h->fp_flag,
+                           (int16_t*)d_disp, n, *p, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, const sbm_fpga_params* p,
+                            void* d_disp, int sync) {
+  if (!h || !d_left || !d_right || !p || !d_disp) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  int st = sbm_fpga_params_validate(p);
+  if (st != SBM_OK) return st;
+  if (n > 65534) return SBM_ERR_UNSUPPORTED;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  st = ensure_fpga(h, n, p->width, p->height, true);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_left, h->fp_xs_l, n, p->width, p->height, 1, 31, h->stream));
+  HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_right, h->fp_xs_r, n, p->width, p->height, 1, 31, h->stream));
+  HIPCHK(h, launch_fpga_bm(h->fp_xs_l, h->fp_xs_r, h->fp_pad_l, h->fp_pad_r, h->fp_rec, h->fp_flag, (int16_t*)d_disp, n, *p,
+                           h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
 }

@@ -67,6 +67,11 @@ hipError_t launch_rect_map(const sbm_rect_cam& cam, int W, int H, int16_t* d_map
 hipError_t launch_rect_remap(const uint8_t* d_src, const int16_t* d_map, uint8_t* d_dst, int n, int W, int H,
                              hipStream_t s);
 
+// FPGA-flavour matcher (sbm_fpga.hip). pad_l/pad_r: n * fpga_pitch(W) * H + 64 bytes each; rec: n*sad_hgt*sad_wdt*8 bytes.
+int fpga_pitch(int W);
+hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, uint8_t* pad_l, uint8_t* pad_r, void* rec, int* flag,
+                          int16_t* disp, int n, const sbm_fpga_params& p, hipStream_t s);
+
 // Consumers of the map (sbm_consume.hip): decimation, reprojection, keypoint depth.
 hipError_t launch_disp_to_float(const int16_t* disp, float* out, size_t count, hipStream_t s);
 hipError_t launch_decimate(const int16_t* disp, int16_t* out, int n, int W, int H, int scale, hipStream_t s);

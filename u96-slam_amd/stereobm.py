@@ -64,6 +64,34 @@ PREFILTER_FLAVOUR_CV = 0
 PREFILTER_FLAVOUR_RTL = 1
 
 
+class FpgaParams(ctypes.Structure):
+    """`sbm_fpga_params` of include/sbm.h: the fields of the BM register block (struct FPGA_REG_BM,
+    src/StereoBM/src/fpga.h:154-169) as decoded by src/dvp/rtl/bm.v:172-193."""
+
+    _fields_ = [(k, ctypes.c_int32) for k in ("width", "height", "block_size", "num_disparities", "uni_enable", "uni_mode",
+                                              "uni_threshold")]
+
+
+def fpga_params(width, height, block_size=21, num_disparities=64, uni_enable=0, uni_mode=0, uni_threshold=0):
+    return FpgaParams(width, height, block_size, num_disparities, uni_enable, uni_mode, uni_threshold)
+
+
+def fpga_params_from_regs(image_size, bm_setting, uni_filt_ctrl=0):
+    """ImageSize [1708h], BmSetting [170Ch], UniFiltCtrl [1728h] -> FpgaParams (firmware: fpga.c:155,158)."""
+    q = FpgaParams()
+    _check(load_library().sbm_fpga_params_from_regs(image_size, bm_setting, uni_filt_ctrl, ctypes.byref(q)))
+    return q
+
+
+def fpga_sad_size_reg(params):
+    """Read-back value of SAD_Size [1724h] (bm.v:208)."""
+    return int(load_library().sbm_fpga_sad_size_reg(ctypes.byref(params)))
+
+
+def fpga_validate(params):
+    return int(load_library().sbm_fpga_params_validate(ctypes.byref(params)))
+
+
 class StereoBMError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"sbm status {code}: {message}")
@@ -115,6 +143,14 @@ def load_library():
     L.sbm_rect_map_device.argtypes = [vp, ctypes.POINTER(RectCam), ci, ci, vp, ci]
     L.sbm_rect_remap_device.argtypes = [vp, ci, vp, vp, ci, ci, vp, ci]
     L.sbm_prefilter_device.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci]
+    fp = ctypes.POINTER(FpgaParams)
+    u32 = ctypes.c_uint32
+    L.sbm_fpga_params_from_regs.argtypes = [u32, u32, u32, fp]
+    L.sbm_fpga_sad_size_reg.argtypes = [fp]
+    L.sbm_fpga_sad_size_reg.restype = u32
+    L.sbm_fpga_params_validate.argtypes = [fp]
+    L.sbm_fpga_bm_device.argtypes = [vp, ci, vp, vp, fp, vp, ci]
+    L.sbm_fpga_compute_device.argtypes = [vp, ci, vp, vp, fp, vp, ci]
     L.sbm_stream.argtypes = [vp]
     L.sbm_stream.restype = vp
     L.sbm_strerror.argtypes = [ci]
@@ -349,6 +385,30 @@ class StereoBM:
         _check(self._L.sbm_prefilter_device(self._h, n, src.data_ptr(), w, h, flavour,
                                             self._p.prefilter_cap if cap is None else cap, out.data_ptr(), 1), self._h)
         return out
+
+    # ---- the reference's own matcher: FPGA flavour (src/dvp/rtl/bm*.v; FPGA.cpp:270-279 consumers) ---------------------
+    def _fpga(self, fn, a, b, params):
+        import torch
+
+        if a.shape != b.shape or a.dtype != torch.uint8 or b.dtype != torch.uint8 or not a.is_cuda or not b.is_cuda:
+            raise StereoBMError(-2, "both inputs must be CUDA uint8 tensors of the same shape")
+        a, b = a.contiguous(), b.contiguous()
+        h, w = a.shape[-2], a.shape[-1]
+        if (w, h) != (params.width, params.height):
+            raise StereoBMError(-2, f"images are {w}x{h}, ImageSize says {params.width}x{params.height}")
+        n = 1 if a.dim() == 2 else a.shape[0]
+        out = torch.empty(a.shape, dtype=torch.int16, device=a.device)
+        torch.cuda.current_stream(a.device).synchronize()
+        _check(fn(self._h, n, a.data_ptr(), b.data_ptr(), ctypes.byref(params), out.data_ptr(), 1), self._h)
+        return out
+
+    def fpga_bm(self, xsbl_l, xsbl_r, params):
+        """RTL block matcher on x-Sobel planes (torch CUDA uint8, (n,H,W) or (H,W)) -> int16 s11.4, -1 = none."""
+        return self._fpga(self._L.sbm_fpga_bm_device, xsbl_l, xsbl_r, params)
+
+    def fpga_compute(self, left, right, params):
+        """xsbl2.v prefilter + RTL block matcher on rectified frames: the PL pipeline behind Fpga::receiveDepthMap."""
+        return self._fpga(self._L.sbm_fpga_compute_device, left, right, params)
 
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
