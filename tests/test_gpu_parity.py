@@ -502,3 +502,27 @@ def test_cpp_inputarray_overload_compiles_when_opencv_is_present(tmp_path, pkg):
         pytest.skip("no OpenCV headers on this box (opencv2/core.hpp not found): the cv::InputArray overload cannot be compiled here")
     exe, r = _build_callsite(tmp_path, pkg, extra=("-DSBM_TEST_WITH_OPENCV", "-lopencv_core"))
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_output_buffer_validation(pkg, torch_cuda):
+    """A caller-supplied disparity buffer reaches the C-ABI as a raw pointer: wrong dtype / shape / device / layout must
+    be refused before that."""
+    torch = torch_cuda
+    bm = pkg.StereoBM.create(32, 9)
+    L = torch.zeros((2, 64, 160), dtype=torch.uint8, device="cuda:0")
+    good = torch.empty((2, 64, 160), dtype=torch.int16, device="cuda:0")
+    assert bm.compute_device(L, L, good) is good
+    for bad in (torch.empty((2, 64, 160), dtype=torch.int32, device="cuda:0"), torch.empty((2, 64, 159), dtype=torch.int16, device="cuda:0"),
+                torch.empty((2, 64, 160), dtype=torch.int16), torch.empty((2, 64, 320), dtype=torch.int16, device="cuda:0")[:, :, ::2]):
+        with pytest.raises(pkg.StereoBMError):
+            bm.compute_device(L, L, bad)
+    Ln = np.zeros((64, 160), np.uint8)
+    for bad in (np.empty((64, 160), np.int32), np.empty((63, 160), np.int16), np.empty((64, 320), np.int16)[:, ::2]):
+        with pytest.raises(pkg.StereoBMError):
+            bm.compute(Ln, Ln, bad)
+    with pytest.raises(pkg.StereoBMError):
+        bm.compute(Ln[::-1], Ln, None)          # negative row stride
+    d = bm.compute_device(L, L, sync=False)      # async: the wrapper keeps the buffers alive until synchronize()
+    bm.synchronize()
+    assert d.shape == L.shape

@@ -9,6 +9,8 @@
 // HBM-bound: 1 byte read + 1 byte written per pixel (the three source rows of a strip hit in L2). Each thread
 // produces 16 adjacent pixels from three unaligned 16+4-byte loads (SWAR vertical sums) and stores 16 bytes. The result is written with
 // a +1 bias into a zero-padded plane (see kPfBias in sbm_common.h).
+#include <stdlib.h>
+
 #include "sbm_common.h"
 
 namespace sbm {
@@ -48,9 +50,8 @@ __device__ __forceinline__ uint32_t diff_clip(uint32_t a, uint32_t b, s16x2 lo, 
 
 // Each thread produces a 16-pixel x PF_ROWS-row tile: PF_ROWS + 2 source row pieces are loaded once and every
 // vertical 1-2-1 sum reuses them (1.5 loads per output row instead of 3).
-constexpr int PF_ROWS = 4;
-
 // grid: x = ceil(ceil(H/PF_ROWS)*ceil(W/16)/256), y = 2*n (image index: even = left, odd = right)
+template <int PF_ROWS>
 __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                         uint8_t* __restrict__ pf_l, uint8_t* __restrict__ pf_r, int W, int H,
                                                         int pitch, int padl, size_t sstride, size_t plane, size_t extent_l,
@@ -178,14 +179,27 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
   }
 }
 
+// Rows per thread tile (PF_ROWS + 2 row pieces are loaded for PF_ROWS output rows). Measured on MI355X
+// (tools/bench_prefilter.py, profiles/r02_prefilter.json): 4 rows is best while source + destination fit the 256 MB
+// Infinity Cache (4.3 vs 4.0 TB/s at 119 MB), 8 rows beyond it (4.4-4.9 vs 4.1-4.5 TB/s at 1.9-2.1 GB, i.e. 98-105 % of
+// the runtime's device-to-device copy of the same bytes). SBM_PF_ROWS=2|4|8 overrides.
+static int pf_rows(size_t bytes_in_out) {
+  static const int env = [] { const char* e = getenv("SBM_PF_ROWS"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 8) ? v : 0; }();
+  if (env) return env;
+  return bytes_in_out > ((size_t)256 << 20) ? 8 : 4;
+}
+
 hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
                             const Geom& g, hipStream_t s) {
   const int npiece = (g.W + 15) / 16;
-  const int ngroup = (g.H + PF_ROWS - 1) / PF_ROWS;
+  const int rows = pf_rows((size_t)4 * g.n * g.W * g.H);
+  const int ngroup = (g.H + rows - 1) / rows;
   dim3 grid((npiece * ngroup + 255) / 256, 2 * g.n);
   const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0};
-  hipLaunchKernelGGL(prefilter_kernel, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl,
-                     (size_t)g.W * g.H, (size_t)g.plane, (size_t)g.n * g.W * g.H, (size_t)g.n * g.W * g.H, m);
+#define SBM_PF(R) hipLaunchKernelGGL(prefilter_kernel<R>, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl, \
+                     (size_t)g.W * g.H, (size_t)g.plane, (size_t)g.n * g.W * g.H, (size_t)g.n * g.W * g.H, m)
+  if (rows == 2) SBM_PF(2); else if (rows == 8) SBM_PF(8); else SBM_PF(4);
+#undef SBM_PF
   return hipGetLastError();
 }
 
@@ -258,20 +272,26 @@ hipError_t launch_prefilter_norm(const uint8_t* d_left, const uint8_t* d_right, 
 hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, int W, int H, int rtl, int cap,
                                   hipStream_t s) {
   const int npiece = (W + 15) / 16;
-  const int ngroup = (H + PF_ROWS - 1) / PF_ROWS;
+  const int rows = pf_rows((size_t)2 * n * W * H);
+  const int ngroup = (H + rows - 1) / rows;
   // the kernel addresses images as (pair, side): image j = pair j/2, side j&1, so a dense array of images is a
   // sequence of pairs with a stride of two images; an odd last image goes in a second launch of one side
   const PfMap m = rtl ? PfMap{-32, 31, 32, 0, 1} : PfMap{-cap, cap, cap, 0, 0};
   const size_t img = (size_t)W * H;
   const unsigned gx = (unsigned)((npiece * ngroup + 255) / 256);
-  if (n >= 2)
-    hipLaunchKernelGGL(prefilter_kernel, dim3(gx, 2 * (n / 2)), dim3(256), 0, s, d_src, d_src + img, d_dst, d_dst + img,
-                       W, H, W, 0, 2 * img, 2 * img, (size_t)(n & ~1) * img, (size_t)(n & ~1) * img - img, m);
-  if (n & 1) {
-    const size_t o = (size_t)(n - 1) * img;
-    hipLaunchKernelGGL(prefilter_kernel, dim3(gx, 1), dim3(256), 0, s, d_src + o, d_src + o, d_dst + o, d_dst + o, W, H, W,
-                       0, img, img, img, img, m);
-  }
+#define SBM_PFD(R)                                                                                                          \
+  do {                                                                                                                      \
+    if (n >= 2)                                                                                                             \
+      hipLaunchKernelGGL(prefilter_kernel<R>, dim3(gx, 2 * (n / 2)), dim3(256), 0, s, d_src, d_src + img, d_dst, d_dst + img, \
+                         W, H, W, 0, 2 * img, 2 * img, (size_t)(n & ~1) * img, (size_t)(n & ~1) * img - img, m);            \
+    if (n & 1) {                                                                                                            \
+      const size_t o = (size_t)(n - 1) * img;                                                                               \
+      hipLaunchKernelGGL(prefilter_kernel<R>, dim3(gx, 1), dim3(256), 0, s, d_src + o, d_src + o, d_dst + o, d_dst + o, W, H, \
+                         W, 0, img, img, img, img, m);                                                                      \
+    }                                                                                                                       \
+  } while (0)
+  if (rows == 2) SBM_PFD(2); else if (rows == 8) SBM_PFD(8); else SBM_PFD(4);
+#undef SBM_PFD
   return hipGetLastError();
 }
 

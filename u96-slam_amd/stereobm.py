@@ -180,6 +180,7 @@ class StereoBM:
         L.sbm_params_default(ctypes.byref(self._p), numDisparities, blockSize)
         self._h = ctypes.c_void_p()
         self._device = device
+        self._inflight = None
         _check(L.sbm_create(ctypes.byref(self._h), ctypes.byref(self._p), device))
 
     @staticmethod
@@ -261,8 +262,15 @@ class StereoBM:
             return a
         L3, R3 = rows(L3), rows(R3)
         out = disparity if disparity is not None else np.empty(L3.shape, np.int16)
+        if not isinstance(out, np.ndarray) or out.dtype != np.int16:
+            raise StereoBMError(-2, "disparity must be a numpy int16 array")
         out3 = out[None] if out.ndim == 2 else out
-        assert out3.shape == L3.shape and out3.dtype == np.int16 and out3.strides[-1] == 2
+        if out3.shape != L3.shape or not out.flags.writeable:
+            raise StereoBMError(-2, f"disparity has shape {out.shape}, the images {left.shape}")
+        # strides travel to C as size_t: rows must be dense and every row stride positive and at least one row long
+        for a, item in ((L3, 1), (R3, 1), (out3, 2)):
+            if a.strides[-1] != item or a.strides[-2] < a.shape[-1] * item or (a.ndim == 3 and a.shape[0] > 1 and a.strides[0] <= 0):
+                raise StereoBMError(-2, "rows must be dense with a positive row stride (negative or overlapping strides are not supported)")
         vp = ctypes.c_void_p
         lp = (vp * n)(*[L3[i].ctypes.data for i in range(n)])
         rp = (vp * n)(*[R3[i].ctypes.data for i in range(n)])
@@ -281,16 +289,26 @@ class StereoBM:
             raise StereoBMError(-2, "Both input images must be CUDA uint8 tensors")
         if left.device.index != self._device:
             raise StereoBMError(-20, f"tensor on cuda:{left.device.index}, engine on device {self._device}")
+        if left.dim() not in (2, 3):
+            raise StereoBMError(-2, "expected (H,W) or (n,H,W) images")
         left, right = left.contiguous(), right.contiguous()
         shape = left.shape
         n = 1 if left.dim() == 2 else shape[0]
         h, w = shape[-2], shape[-1]
         if disparity is None:
             disparity = torch.empty(shape, dtype=torch.int16, device=left.device)
-        # the engine runs on its own stream: order it behind whatever produced the inputs
+        elif (not isinstance(disparity, torch.Tensor) or disparity.dtype != torch.int16 or not disparity.is_cuda
+              or disparity.device != left.device or tuple(disparity.shape) != tuple(shape) or not disparity.is_contiguous()):
+            # the C-ABI writes n*h*w int16 through the raw pointer: anything else would be an out-of-bounds / strided-wrong write
+            raise StereoBMError(-2, f"disparity must be a contiguous CUDA int16 tensor of shape {tuple(shape)} on {left.device}")
+        # the engine runs on its own (non-blocking) stream: order it behind whatever produced the inputs
         torch.cuda.current_stream(left.device).synchronize()
         _check(self._L.sbm_compute_device(self._h, n, left.data_ptr(), right.data_ptr(), w, h, disparity.data_ptr(),
                                           1 if sync else 0), self._h)
+        if not sync:
+            # torch's caching allocator only knows its own streams: without this the .contiguous() temporaries and a
+            # freshly allocated output could be handed out again while the engine's kernels still use them
+            self._inflight = (left, right, disparity)
         return disparity
 
     def launch_raw(self, n, d_left, d_right, w, h, d_disp, sync=False):
@@ -412,6 +430,7 @@ class StereoBM:
 
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
+        self._inflight = None   # buffers of an asynchronous compute_device may be released now
 
     def stream(self):
         return self._L.sbm_stream(self._h)
