@@ -264,12 +264,16 @@ def main():
                 tj = json.loads(tfile.read_text())
                 key = f"{args.workload}_w{wsz}_b{B}"
                 if key in tj:
-                    traffic = tj[key]["bytes_per_launch"]
+                    traffic = tj[key].get("bytes_per_launch")
                     # what actually bounds the kernel: VALU issue, from the same committed PMC run
-                    pmc_extra = {k: tj[key][k] for k in ("valu_busy_frac", "lds_busy_frac") if k in tj[key]}
+                    pmc_extra = {k: tj[key][k] for k in ("valu_busy_frac", "lds_busy_frac", "lane_ops_per_pixel_disparity") if k in tj[key]}
+                    pmc_extra["traffic_from"] = f"{tj[key].get('source')} ({tj[key].get('date', 'round 1')}, commit {tj[key].get('commit', '?')}), not this run"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "sad_fast_kernel" if stage == "sad" else "sad_generic_kernel",
+        # `bound` follows the bench contract ("hbm" | "mfma"): the HBM figure is what north_star asks for; the kernel itself
+        # is limited by VALU issue (`limiter`, `valu_busy_frac`), so `frac` is informational, not a measure of its quality
+        fast_path = prof["sad"] > 0 and prof["border"] < prof["sad"]
+        roofline = {"bound": "hbm", "limiter": "valu", "kernel": "sad_fast_kernel" if fast_path else "sad_generic_kernel (fast path off)",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
@@ -278,9 +282,26 @@ def main():
         # the one stage of the path that IS HBM-bound: the prefilter, 1 B read + 1 B written per pixel and image
         pf_ms = prof.get("prefilter", 0.0)
         pf_bytes = 4.0 * W * H * B
+        # the device's own copy rate for the same bytes (read 2*W*H*B, write the same), measured here with the runtime's
+        # copy kernel: what "HBM-bound" can mean on this box at this working set
+        cp_src = torch.empty((2, B, H, W), dtype=torch.uint8, device=dev)
+        cp_dst = torch.empty_like(cp_src)
+        for _ in range(3):
+            cp_dst.copy_(cp_src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            cp_dst.copy_(cp_src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_ms = e0.elapsed_time(e1) / 20
+        copy_gbs = pf_bytes / (copy_ms * 1e-3) / 1e9 if copy_ms > 0 else 0.0
         roofline_pf = {"bound": "hbm", "kernel": "prefilter_kernel", "achieved": round(pf_bytes / (pf_ms * 1e-3) / 1e9, 2) if pf_ms > 0 else 0.0,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pf_bytes / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pf_ms > 0 else 0.0,
-                       "kernel_ms": round(pf_ms, 4), "algorithmic_bytes_per_launch": pf_bytes}
+                       "kernel_ms": round(pf_ms, 4), "algorithmic_bytes_per_launch": pf_bytes,
+                       "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(pf_bytes / (pf_ms * 1e-3) / 1e9 / copy_gbs, 4) if pf_ms > 0 and copy_gbs > 0 else 0.0,
+                       "note": "kernel_ms is the event-to-event stage time inside the engine (includes ~5 us of launch gap); stand-alone "
+                               "kernel rates inside and beyond the Infinity Cache: profiles/r02_prefilter.json"}
 
         # ---- CPU baseline (reported only) --------------------------------------------------------------------------
         cpu = None
@@ -289,22 +310,44 @@ def main():
 
             cores = max(1, min(usable_cores(), sbm_oracle.max_threads()))
             p = sbm_oracle.make_params(nd, wsz, 31, 0, 10, 10, 50 if post else 0, 32 if post else 0, 1 if post else -1)
-            t1 = time.perf_counter()
-            sbm_oracle.compute_batch(p, Lh[:1], Rh[:1], threads=1)
-            one = time.perf_counter() - t1
-            # about 20 s of single-core work in total, at least one pair per core
-            sample = args.cpu_sample or max(cores, min(8 * cores, int(round(20.0 / max(one, 1e-3)))))
-            idx = [i % B for i in range(sample)]
-            t1 = time.perf_counter()
-            ref = sbm_oracle.compute_batch(p, Lh[idx], Rh[idx], threads=cores)
-            cpu_s = time.perf_counter() - t1
-            cpu = {"value": round(sample * pixdisp_per_pair / cpu_s / 1e6, 2), "unit": "Mpix-disparities/s", "cores": cores,
-                   "kind": "port", "sample": f"{sample} pairs of the same {W}x{H} nd{nd} w{wsz} batch, {cpu_s:.2f} s wall, "
-                   "in-repo C restatement of cv::StereoBM (not OpenCV), OpenMP across pairs"}
-            if args.check:
-                got = dD[: min(sample, B)].cpu().numpy()
-                ok = all(np.array_equal(got[i], ref[i]) for i in range(min(sample, B)) if idx[i] == i)
-                cpu["bit_exact_vs_gpu"] = bool(ok)
+            cv2, cv_status = probe_opencv()
+            if cv2 is not None:
+                # the real cv::StereoBM of this host: checker for the GPU output and CPU baseline
+                cv2.setNumThreads(cores)
+                m = cv2.StereoBM_create(numDisparities=nd, blockSize=wsz)
+                m.setPreFilterCap(31); m.setMinDisparity(0); m.setTextureThreshold(10); m.setUniquenessRatio(10)
+                if post:
+                    m.setSpeckleWindowSize(50); m.setSpeckleRange(32); m.setDisp12MaxDiff(1)
+                t1 = time.perf_counter()
+                m.compute(Lh[0], Rh[0])
+                one = time.perf_counter() - t1
+                sample = args.cpu_sample or max(4, min(B, int(round(15.0 / max(one, 1e-3)))))
+                got = dD[:min(sample, B)].cpu().numpy()
+                t1 = time.perf_counter()
+                ref = [m.compute(Lh[i % B], Rh[i % B]) for i in range(sample)]
+                cpu_s = time.perf_counter() - t1
+                exact = all(np.array_equal(got[i], ref[i]) for i in range(min(sample, B)))
+                cpu = {"value": round(sample * pixdisp_per_pair / cpu_s / 1e6, 2), "unit": "Mpix-disparities/s", "cores": cores,
+                       "kind": "reference", "opencv": cv_status, "bit_exact_vs_gpu": bool(exact),
+                       "sample": f"{sample} pairs of the same {W}x{H} nd{nd} w{wsz} batch, {cpu_s:.2f} s wall, cv2.StereoBM with cv2.setNumThreads({cores})"}
+            else:
+                t1 = time.perf_counter()
+                sbm_oracle.compute_batch(p, Lh[:1], Rh[:1], threads=1)
+                one = time.perf_counter() - t1
+                # about 20 s of single-core work in total, at least one pair per core
+                sample = args.cpu_sample or max(cores, min(8 * cores, int(round(20.0 / max(one, 1e-3)))))
+                idx = [i % B for i in range(sample)]
+                t1 = time.perf_counter()
+                ref = sbm_oracle.compute_batch(p, Lh[idx], Rh[idx], threads=cores)
+                cpu_s = time.perf_counter() - t1
+                cpu = {"value": round(sample * pixdisp_per_pair / cpu_s / 1e6, 2), "unit": "Mpix-disparities/s", "cores": cores,
+                       "kind": "port", "opencv": cv_status,
+                       "sample": f"{sample} pairs of the same {W}x{H} nd{nd} w{wsz} batch, {cpu_s:.2f} s wall, "
+                       "in-repo C restatement of cv::StereoBM (not OpenCV), OpenMP across pairs"}
+                if args.check:
+                    got = dD[: min(sample, B)].cpu().numpy()
+                    ok = all(np.array_equal(got[i], ref[i]) for i in range(min(sample, B)) if idx[i] == i)
+                    cpu["bit_exact_vs_gpu"] = bool(ok)
 
         out = {
             "metric": "Mpix-disparities/s", "value": round(value, 2), "unit": "Mpix-disparities/s", "n_gpus": world,

@@ -24,27 +24,44 @@ def main():
         f = run / f"bench_{src}.json"
         if f.exists():
             (prof / f"{rnd}_bench_{dst}.json").write_text(json.dumps(last_json(f)) + "\n")
-    pmc = json.loads((run / "summary_pmc.json").read_text())
-    bench = last_json(run / "bench_plain.json")
-    B = bench["config"]["pairs_per_gpu_per_step"]
-    name = next(k for k in pmc if "sad_fast_kernel" in k)
-    e = pmc[name]
-    fetch, write = e["FETCH_SIZE"]["mean"], e["WRITE_SIZE"]["mean"]
-    valu = 4.0 * e["SQ_ACTIVE_INST_VALU"]["mean"] / (1024 * e["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
-    lds = 4.0 * e["SQ_ACTIVE_INST_LDS"]["mean"] / (1024 * e["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
-    tj = {
-        f"kitti_w15_b{B}": {
-            "kernel": name,
-            "bytes_per_launch": int(round((2 * fetch + write) * 1024)),
-            "fetch_size_kb": fetch,
-            "write_size_kb": write,
-            "correction": "2*FETCH_SIZE + WRITE_SIZE (profiles/hbm_calibration.json)",
-            "valu_busy_frac": round(valu, 4),
-            "lds_busy_frac": round(lds, 4),
-            "valu_busy_formula": "4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs)",
-            "source": f"profiles/{rnd}_kitti_b64_pmc.json",
-        }
-    }
+    import datetime
+    import subprocess
+
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=prof.parent).stdout.strip()
+    except Exception:
+        commit = "?"
+    stamp = datetime.date.today().isoformat()
+    shapes = {"kitti": (1242, 375, 128), "fhd": (1920, 1080, 256), "uhd": (3840, 2160, 256)}
+    tj = {}
+    for wl, pmcfile, benchfile, tag in (("kitti", run / "summary_pmc.json", run / "bench_plain.json", f"{rnd}_kitti_b64_pmc.json"),
+                                        ("fhd", run / "summary_fhd_pmc.json", run / "bench_fhd.json", f"{rnd}_fhd_pmc.json"),
+                                        ("uhd", run / "summary_uhd_pmc.json", run / "bench_uhd.json", f"{rnd}_uhd_pmc.json")):
+        if not pmcfile.exists() or not benchfile.exists():
+            continue
+        pmc = json.loads(pmcfile.read_text())
+        if wl != "kitti":
+            shutil.copy(pmcfile, prof / tag)
+        bench = last_json(benchfile)
+        B = bench["config"]["pairs_per_gpu_per_step"]
+        wsz = int(bench["config"]["workload"].split(" SAD")[0].split(", ")[-1].split("x")[0])
+        name = next(k for k in pmc if "sad_fast_kernel" in k)
+        e = pmc[name]
+        W, H, nd = shapes[wl]
+        ent = {"kernel": name, "source": f"profiles/{tag}", "date": stamp, "commit": commit}
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            fetch, write = e["FETCH_SIZE"]["mean"], e["WRITE_SIZE"]["mean"]
+            ent.update({"bytes_per_launch": int(round((2 * fetch + write) * 1024)), "fetch_size_kb": fetch, "write_size_kb": write,
+                        "correction": "2*FETCH_SIZE + WRITE_SIZE (profiles/hbm_calibration.json)"})
+        if "SQ_ACTIVE_INST_VALU" in e and "GRBM_GUI_ACTIVE" in e:
+            ent["valu_busy_frac"] = round(4.0 * e["SQ_ACTIVE_INST_VALU"]["mean"] / (1024 * e["GRBM_GUI_ACTIVE"]["mean"] / 8.0), 4)
+            ent["valu_busy_formula"] = "4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs)"
+        if "SQ_ACTIVE_INST_LDS" in e and "GRBM_GUI_ACTIVE" in e:
+            ent["lds_busy_frac"] = round(4.0 * e["SQ_ACTIVE_INST_LDS"]["mean"] / (1024 * e["GRBM_GUI_ACTIVE"]["mean"] / 8.0), 4)
+        if "SQ_INSTS_VALU" in e:
+            ent["valu_wave_instructions_per_launch"] = e["SQ_INSTS_VALU"]["mean"]
+            ent["lane_ops_per_pixel_disparity"] = round(e["SQ_INSTS_VALU"]["mean"] * 64.0 / (float(B) * W * H * nd), 3)
+        tj[f"{wl}_w{wsz}_b{B}"] = ent
     (prof / "hbm_traffic.json").write_text(json.dumps(tj, indent=1) + "\n")
     print(json.dumps(tj, indent=1))
 
