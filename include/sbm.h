@@ -249,6 +249,16 @@ int sbm_fpga_bm_device(sbm_handle* h, int n, const void* d_xsbl_l, const void* d
 int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, const sbm_fpga_params* p,
                             void* d_disp, int sync);
 
+/* ---- GFTT minimum-eigenvalue map of the PL ----------------------------------------------------------
+ * The dense half of the reference's FPGA feature detector (src/dvp/rtl/gftt_sbl.v, gftt_box.v, gftt_eig.v, gftt_obuf.v):
+ * per image a height*width uint16 map of (a + c) - sqrt((a - c)^2 + 4 b^2) over 3x3 boxes of the Sobel products, rows
+ * 0, 1, H-2, H-1 and columns 0, W-1 = 0, plus the maximum of the map (the GFTT `Max` register) -- exactly what
+ * generateKeypoints2() consumes (src/slam/src/core/GFTT.cpp:41-170, fed by FPGA.cpp:283-291). Fixed-point steps and
+ * limiters follow the RTL; its CORDIC square root is specified to +-1 LSB, this engine returns the exact floor.
+ * d_img: n dense u8 images (the rectified left frames already on the device); d_eig: n*height*width uint16;
+ * d_max: n uint32. width 3..1023, height 5..511 (the RTL's field widths). */
+int sbm_gftt_eig_device(sbm_handle* h, int n, const void* d_img, int width, int height, void* d_eig, void* d_max, int sync);
+
 /* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours (record an event on it
  * after sbm_compute_device(..., sync = 0)) or ours behind theirs (hipStreamWaitEvent on it before the call). Every entry
  * point selects the handle's device for the duration of the call and restores the caller's current device on return. */

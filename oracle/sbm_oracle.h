@@ -124,6 +124,11 @@ int sbmo_fpga_bm(const uint8_t* xl, const uint8_t* xr, int width, int height, in
 int sbmo_fpga_compute(const uint8_t* left, const uint8_t* right, int width, int height, int wsz, int ndisp, int uni_enb,
                       int uni_mode, int uni_thr, int16_t* disp);
 
+/* GFTT minimum-eigenvalue map of the PL (gftt_sbl.v, gftt_box.v, gftt_eig.v, gftt_obuf.v). eig: dense
+ * height*width uint16 (rows 0,1,H-2,H-1 = 0), max_out: the value of the GFTT `Max` register. PARITY UNPINNED; the square
+ * root is taken as the exact floor (the CORDIC core's last bit is unspecified: +-1 LSB tolerance downstream). */
+int sbmo_gftt_eig(const uint8_t* img, int width, int height, uint16_t* eig, uint32_t* max_out);
+
 int sbmo_max_threads(void);
 
 #ifdef __cplusplus

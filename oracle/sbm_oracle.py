@@ -154,6 +154,8 @@ def lib():
         L.sbmo_fpga_bm.restype = ci
         L.sbmo_fpga_compute.argtypes = [u8p, u8p, ci, ci, ci, ci, ci, ci, ci, i16p]
         L.sbmo_fpga_compute.restype = ci
+        L.sbmo_gftt_eig.argtypes = [u8p, ci, ci, u16p, ctypes.POINTER(u32)]
+        L.sbmo_gftt_eig.restype = ci
         _LIB = L
     return _LIB
 
@@ -376,3 +378,15 @@ def fpga_compute(left, right, wsz, ndisp, uni_enb=0, uni_mode=0, uni_thr=0):
     if st != 0:
         raise ValueError(f"oracle status {st}")
     return d
+
+
+def gftt_eig(img):
+    """PL min-eigenvalue map (uint16 HxW) and the `Max` register value; exact-floor square root."""
+    img = _u8(img)
+    h, w = img.shape
+    e = np.empty((h, w), np.uint16)
+    m = ctypes.c_uint32()
+    st = lib().sbmo_gftt_eig(_p(img, ctypes.c_uint8), w, h, _p(e, ctypes.c_uint16), ctypes.byref(m))
+    if st != 0:
+        raise ValueError(f"oracle status {st}")
+    return e, int(m.value)

@@ -301,3 +301,79 @@ int sbmo_fpga_compute(const uint8_t* left, const uint8_t* right, int width, int 
   free(xr);
   return r;
 }
+
+/* ==== GFTT minimum-eigenvalue map of the PL: src/dvp/rtl/gftt_sbl.v, gftt_box.v, gftt_eig.v,
+ * placement and `max` register gftt_obuf.v, consumer src/slam/src/core/GFTT.cpp:41-170 (reads the map as CV_16UC1 plus the
+ * register value, FPGA.cpp:283-291). PARITY UNPINNED (no golden map in the reference, no simulator), and the square root is
+ * a Xilinx CORDIC core (src/dvp/ip/gftt_sqrt/gftt_sqrt.xci: Square_Root, UnsignedFraction, 32 -> 17 bits, Truncate) whose
+ * last bit is not specified: this restatement takes the exact floor and the GPU test allows +-1 LSB on the map.
+ *
+ * Derived from the pipeline timing (all line RAMs have 1-cycle reads):
+ *   Sobel (gftt_sbl.v:113-204), defined for image rows 1..H-2: sample t of a row is centred on column t,
+ *     dx = sum_k w_k (p[y+k][x+1] - p[y+k][x-1]), dy = sum_j w_j (p[y+1][x+j] - p[y-1][x+j]), w = (1,2,1); both forced to 0
+ *     at x = 0 and x = W-1 (first_r / last_r).
+ *   products (gftt_eig.v:122-143): |dx|^2 >> 6, |dy|^2 >> 6, |dx|*|dy| >> 6  (absolute values: the sign of dx*dy is dropped)
+ *   box (gftt_box.v): horizontal 3-sum centred on the sample, forced to 0 in the first and last column, then the sum
+ *     of three consecutive Sobel rows centred on the middle one, saturated to 16 bits -> a, c, b; defined for rows 2..H-3
+ *   eig (gftt_eig.v:226-362): (a + c) - sqrt(((a-c)^2 >> 10) + (b^2 >> 8)), the radicand saturated to 22 bits; the CORDIC
+ *     result is floor(sqrt(radicand << 10)) in the units of a + c; negative -> 0, above 16 bits -> 0xFFFF
+ *   output (gftt_obuf.v:295-305): rows 2..H-3 of a dense H x W uint16 map, every other row keeps the firmware's 0 fill
+ *     (fpga.c:107-108); max = largest value written (gftt_obuf.v:101-130). */
+static uint32_t isqrt64(uint64_t n) {
+  uint64_t r = 0, bit = 1ull << 62;
+  while (bit > n) bit >>= 2;
+  while (bit) {
+    if (n >= r + bit) { n -= r + bit; r = (r >> 1) + bit; } else { r >>= 1; }
+    bit >>= 2;
+  }
+  return (uint32_t)r;
+}
+
+int sbmo_gftt_eig(const uint8_t* img, int width, int height, uint16_t* eig, uint32_t* max_out) {
+  if (!img || !eig) return SBM_ERR_NULL;
+  if (width < 3 || height < 5 || width > 1023 || height > 511) return SBM_ERR_SIZE;
+  const int W = width, H = height;
+  memset(eig, 0, (size_t)W * H * sizeof(uint16_t));
+  uint32_t* hs = (uint32_t*)calloc((size_t)3 * W * H, sizeof(uint32_t));   /* horizontal 3-sums of the three products */
+  if (!hs) return SBM_ERR_NOMEM;
+  uint32_t* v = (uint32_t*)calloc((size_t)3 * W, sizeof(uint32_t));
+  if (!v) { free(hs); return SBM_ERR_NOMEM; }
+  for (int y = 1; y <= H - 2; y++) {
+    const uint8_t *r0 = img + (size_t)(y - 1) * W, *r1 = img + (size_t)y * W, *r2 = img + (size_t)(y + 1) * W;
+    for (int x = 0; x < W; x++) {
+      int dx = 0, dy = 0;
+      if (x > 0 && x < W - 1) {
+        dx = (r0[x + 1] - r0[x - 1]) + 2 * (r1[x + 1] - r1[x - 1]) + (r2[x + 1] - r2[x - 1]);
+        dy = (r2[x - 1] - r0[x - 1]) + 2 * (r2[x] - r0[x]) + (r2[x + 1] - r0[x + 1]);
+      }
+      const uint32_t ax = (uint32_t)abs(dx), ay = (uint32_t)abs(dy);
+      v[x] = ((ax * ax) >> 6) & 0xffffu; v[W + x] = ((ay * ay) >> 6) & 0xffffu; v[2 * W + x] = ((ax * ay) >> 6) & 0xffffu;
+    }
+    for (int k = 0; k < 3; k++)
+      for (int x = 1; x < W - 1; x++) hs[((size_t)k * H + y) * W + x] = v[k * W + x - 1] + v[k * W + x] + v[k * W + x + 1];
+  }
+  uint32_t mx = 0;
+  for (int y = 2; y <= H - 3; y++)
+    for (int x = 0; x < W; x++) {
+      uint32_t abc[3];
+      for (int k = 0; k < 3; k++) {
+        const uint32_t s = hs[((size_t)k * H + y - 1) * W + x] + hs[((size_t)k * H + y) * W + x] + hs[((size_t)k * H + y + 1) * W + x];
+        abc[k] = s > 0xffffu ? 0xffffu : s;                                   /* gftt_box.v: lim */
+      }
+      const uint32_t a = abc[0], c = abc[1], b = abc[2];
+      const uint32_t apc = a + c, amc = a > c ? a - c : c - a;
+      const uint32_t amc2 = (uint32_t)(((uint64_t)amc * amc) >> 10) & 0x3fffffu;   /* [31:10] */
+      const uint32_t b2 = (uint32_t)(((uint64_t)b * b) >> 8) & 0xffffffu;           /* [31:8]  */
+      uint32_t s = amc2 + b2;
+      if (s > 0x3fffffu) s = 0x3fffffu;
+      const uint32_t root = isqrt64((uint64_t)s << 10) & 0xffffu;                 /* CORDIC 17-bit result, low 16 bits used */
+      const int32_t e = (int32_t)apc - (int32_t)root;
+      const uint32_t out = e < 0 ? 0u : (e > 0xffff ? 0xffffu : (uint32_t)e);
+      eig[(size_t)y * W + x] = (uint16_t)out;
+      if (out > mx) mx = out;
+    }
+  if (max_out) *max_out = mx;
+  free(v);
+  free(hs);
+  return SBM_OK;
+}

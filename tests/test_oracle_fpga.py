@@ -257,3 +257,28 @@ def test_geometry_and_known_answer(oracle, golden):
     # end-to-end entry: x-Sobel of the rectified pair (== golden xsbl) then the matcher
     de = oracle.fpga_compute(golden["rect_l"], golden["rect_r"], 21, 64)
     assert np.array_equal(de, dd)
+
+
+def test_gftt_oracle_properties(oracle, golden):
+    """PL GFTT map (gftt_sbl / gftt_box / gftt_eig / gftt_obuf restated): geometry the RTL fixes, the Max register, and
+    agreement with a floating-point 2*lambda_min of the same 3x3 structure tensor (fixed-point truncations only)."""
+    from scipy.ndimage import convolve, uniform_filter
+
+    img = golden["rect_l"]
+    e, mx = oracle.gftt_eig(img)
+    assert e.dtype == np.uint16 and e.shape == img.shape and mx == int(e.max())
+    assert (e[:2] == 0).all() and (e[-2:] == 0).all() and (e[:, 0] == 0).all() and (e[:, -1] == 0).all()
+    flat, m0 = oracle.gftt_eig(np.full((40, 50), 77, np.uint8))
+    assert m0 == 0 and not flat.any()
+    f = img.astype(np.float64)
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], float)
+    dx, dy = convolve(f, kx[::-1, ::-1], mode="nearest"), convolve(f, kx.T[::-1, ::-1], mode="nearest")
+    A, C, B = (uniform_filter(t, 3) * 9 / 64 for t in (dx * dx, dy * dy, np.abs(dx * dy)))
+    lam = np.clip((A + C) - np.sqrt((A - C) ** 2 + 4 * B * B), 0, 65535)
+    inner = (slice(4, -4), slice(4, -4))
+    assert np.abs(lam[inner] - e[inner]).mean() < 5 and np.corrcoef(lam[inner].ravel(), e[inner].ravel())[0, 1] > 0.999
+    # an isolated bright corner scores, a straight edge does not (min eigenvalue)
+    t = np.zeros((40, 60), np.uint8)
+    t[20:, 30:] = 200
+    ce, _ = oracle.gftt_eig(t)
+    assert ce[18:23, 28:33].max() > 100 * max(1, int(ce[30, 28:33].max())) or ce[30, 28:33].max() == 0

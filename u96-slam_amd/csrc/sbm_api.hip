@@ -689,6 +689,18 @@ int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void
   return SBM_OK;
 }
 
+int sbm_gftt_eig_device(sbm_handle* h, int n, const void* d_img, int width, int height, void* d_eig, void* d_max, int sync) {
+  if (!h || !d_img || !d_eig || !d_max) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  if (width < 3 || height < 5 || width > 1023 || height > 511) return SBM_ERR_SIZE;
+  if (n > 65535) return SBM_ERR_UNSUPPORTED;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  HIPCHK(h, launch_gftt_eig((const uint8_t*)d_img, (uint16_t*)d_eig, (unsigned*)d_max, n, width, height, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
 int sbm_disparity_to_float_device(sbm_handle* h, int n, const void* d_disp, int width, int height, void* d_out, int sync) {
   if (!h || !d_disp || !d_out) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;

@@ -72,6 +72,9 @@ int fpga_pitch(int W);
 hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, uint8_t* pad_l, uint8_t* pad_r, void* rec, int* flag,
                           int16_t* disp, int n, const sbm_fpga_params& p, hipStream_t s);
 
+// GFTT minimum-eigenvalue map of the PL (sbm_gftt.hip): eig = n*H*W uint16, maxv = n uint32 (`Max` register per image).
+hipError_t launch_gftt_eig(const uint8_t* img, uint16_t* eig, unsigned* maxv, int n, int W, int H, hipStream_t s);
+
 // Consumers of the map (sbm_consume.hip): decimation, reprojection, keypoint depth.
 hipError_t launch_disp_to_float(const int16_t* disp, float* out, size_t count, hipStream_t s);
 hipError_t launch_decimate(const int16_t* disp, int16_t* out, int n, int W, int H, int scale, hipStream_t s);

@@ -151,6 +151,7 @@ def load_library():
     L.sbm_fpga_params_validate.argtypes = [fp]
     L.sbm_fpga_bm_device.argtypes = [vp, ci, vp, vp, fp, vp, ci]
     L.sbm_fpga_compute_device.argtypes = [vp, ci, vp, vp, fp, vp, ci]
+    L.sbm_gftt_eig_device.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci]
     L.sbm_stream.argtypes = [vp]
     L.sbm_stream.restype = vp
     L.sbm_strerror.argtypes = [ci]
@@ -427,6 +428,22 @@ class StereoBM:
     def fpga_compute(self, left, right, params):
         """xsbl2.v prefilter + RTL block matcher on rectified frames: the PL pipeline behind Fpga::receiveDepthMap."""
         return self._fpga(self._L.sbm_fpga_compute_device, left, right, params)
+
+    def gftt_eig(self, img):
+        """PL GFTT min-eigenvalue map of torch CUDA uint8 frames (n,H,W) or (H,W): (int16-viewed uint16 map as torch.int32,
+        per-image maximum) -- the inputs of generateKeypoints2 (src/slam/src/core/GFTT.cpp:41)."""
+        import torch
+
+        if img.dtype != torch.uint8 or not img.is_cuda:
+            raise StereoBMError(-2, "frames must be CUDA uint8 tensors")
+        img = img.contiguous()
+        h, w = img.shape[-2], img.shape[-1]
+        n = 1 if img.dim() == 2 else img.shape[0]
+        eig = torch.empty(img.shape, dtype=torch.int16, device=img.device)     # uint16 payload (torch has no uint16 math)
+        mx = torch.empty((n,), dtype=torch.int32, device=img.device)
+        torch.cuda.current_stream(img.device).synchronize()
+        _check(self._L.sbm_gftt_eig_device(self._h, n, img.data_ptr(), w, h, eig.data_ptr(), mx.data_ptr(), 1), self._h)
+        return eig.to(torch.int32) & 0xffff, mx
 
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
