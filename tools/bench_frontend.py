@@ -64,6 +64,18 @@ def main():
         r["prefilter_rtl"] = timed(lambda: L.sbm_prefilter_device(bm._h, n, src.data_ptr(), W, H, 1, 31, dst.data_ptr(), 0), 2 * npx)
         r["decimate4"] = timed(lambda: L.sbm_decimate_device(bm._h, n, disp.data_ptr(), W, H, 4, dec.data_ptr(), 0), npx // 16 * 4)
         r["reproject_dec4"] = timed(lambda: L.sbm_reproject_device(bm._h, n, dec.data_ptr(), W // 4, H // 4, 4, ctypes.byref(model), 0, xyz.data_ptr(), 0), npx // 16 * 14)
+        # the reference's own PL blocks: GFTT map (1 B in + 2 B out per pixel) and the FPGA-flavour
+        # matcher at the firmware's configuration (window 21, 64 disparities) -- VALU-bound like the cv flavour
+        if W <= 1023 and H <= 511:
+            eig = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+            mx = torch.empty((n,), dtype=torch.int32, device="cuda")
+            r["gftt_eig"] = timed(lambda: L.sbm_gftt_eig_device(bm._h, n, src.data_ptr(), W, H, eig.data_ptr(), mx.data_ptr(), 0), 3 * npx)
+            fp = pkg.fpga_params(W, H, 21, 64)
+            xs = torch.from_numpy(rng.integers(0, 64, (n, H, W), dtype=np.uint8)).cuda()
+            xr = torch.roll(xs, -17, dims=2).contiguous()
+            t = timed(lambda: L.sbm_fpga_bm_device(bm._h, n // 2, xs.data_ptr(), xr.data_ptr(), ctypes.byref(fp), disp.data_ptr(), 0), 4 * (n // 2) * W * H)
+            t["Mpix_disparities_per_s"] = round((n // 2) * W * H * 64 / t["ms"] / 1e3, 1)
+            r["fpga_bm_w21_nd64"] = t
         out.append({name: r})
     print(json.dumps(out))
 
