@@ -352,7 +352,8 @@ def main():
         out = {
             "metric": "Mpix-disparities/s", "value": round(value, 2), "unit": "Mpix-disparities/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": f"synthetic ({uniq} distinct KITTI-style pairs per rank tiled to {B}; SURVEY.md 8d generator)",
             "config": {"workload": f"{args.workload}: {W}x{H} gray, ndisp={nd}, {wsz}x{wsz} SAD, "
                        + ("texture 10 / uniqueness 10 / disp12MaxDiff 1 / speckle 50,32" if post else "texture 10 / uniqueness 10, no LR/speckle"),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, " + (
