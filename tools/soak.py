@@ -57,8 +57,42 @@ def main():
             assert np.array_equal(eng2["disp"], eng["disp"]), "second run differs"
         except AssertionError as e:
             bad.append({"iteration": it, "shape": [n, h, w], "params": kw, "error": str(e)[:200]})
-    print(json.dumps({"iterations": args.iters, "seed": args.seed, "mismatches": len(bad), "seconds": round(time.time() - t0, 1),
-                      "first": bad[:3]}))
+    # ---- the reference's own PL blocks (FPGA-flavour matcher, GFTT map): random sizes / windows / phases / filter settings
+    import torch
+
+    bmf = pkg.StereoBM.create(64, 21)
+    nf = max(10, args.iters // 4)
+    for it in range(nf):
+        wsz = int(rng.choice([3, 5, 9, 15, 21, 27, 31]))
+        nd = int(rng.choice([32, 64, 96, 128, 192, 256]))
+        hw = wsz // 2
+        if (nd + hw + 1) % 32 == 0:
+            continue
+        n = int(rng.choice([1, 2, 3]))
+        h = int(rng.integers(wsz + 2, min(511, wsz + 140)))
+        w = int(rng.integers(nd + wsz + 3, min(1023, nd + wsz + 400)))
+        amp = int(rng.choice([64, 64, 2]))
+        xr = (rng.integers(0, amp, (n, h, w)) * (63 if amp == 2 else 1)).astype(np.uint8)
+        xl = np.stack([np.roll(xr[i], int(rng.integers(0, nd)), axis=1) for i in range(n)])
+        if amp != 2:
+            xl = np.clip(xl.astype(int) + rng.integers(-5, 6, xl.shape), 0, 63).astype(np.uint8)
+        uni = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 1024)))
+        try:
+            fp = pkg.fpga_params(w, h, wsz, nd, *uni)
+            got = bmf.fpga_bm(torch.from_numpy(xl).cuda(), torch.from_numpy(xr).cuda(), fp).cpu().numpy()
+            for i in range(n):
+                ref = oracle.fpga_bm(xl[i], xr[i], wsz, nd, *uni)
+                assert np.array_equal(got[i], ref), f"fpga pair {i}: {(got[i] != ref).sum()} pixels"
+            img = rng.integers(0, 256, (n, h, w), dtype=np.uint8) if h >= 5 else None
+            if img is not None:
+                eig, mx = bmf.gftt_eig(torch.from_numpy(img).cuda())
+                for i in range(n):
+                    re_, rm = oracle.gftt_eig(img[i])
+                    assert np.array_equal(eig[i].cpu().numpy(), re_.astype(np.int64)) and int(mx[i]) == rm, f"gftt image {i}"
+        except AssertionError as e:
+            bad.append({"iteration": f"pl{it}", "shape": [n, h, w], "params": dict(wsz=wsz, nd=nd, uni=uni, amp=amp), "error": str(e)[:200]})
+    print(json.dumps({"iterations": args.iters, "pl_iterations": nf, "seed": args.seed, "mismatches": len(bad),
+                      "seconds": round(time.time() - t0, 1), "first": bad[:3]}))
     sys.exit(1 if bad else 0)
 
 
