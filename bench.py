@@ -282,20 +282,24 @@ def main():
         # the one stage of the path that IS HBM-bound: the prefilter, 1 B read + 1 B written per pixel and image
         pf_ms = prof.get("prefilter", 0.0)
         pf_bytes = 4.0 * W * H * B
-        # the device's own copy rate for the same bytes (read 2*W*H*B, write the same), measured here with the runtime's
-        # copy kernel: what "HBM-bound" can mean on this box at this working set
-        cp_src = torch.empty((2, B, H, W), dtype=torch.uint8, device=dev)
-        cp_dst = torch.empty_like(cp_src)
-        for _ in range(3):
-            cp_dst.copy_(cp_src)
+        # the device's own copy rate for the same bytes (read 2*W*H*B, write the same) with the runtime's copy kernel, cycling
+        # through enough buffers (> 512 MB) that the copies come from HBM like the prefilter's inputs do inside a step --
+        # a single 119 MB buffer pair would sit in the 256 MB Infinity Cache and flatter the reference
+        nbuf = max(2, int(-(-(768 << 20) // max(1, 4 * B * H * W))))
+        cp_src = [torch.empty((2, B, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        cp_dst = [torch.empty((2, B, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        for i in range(nbuf):
+            cp_dst[i].copy_(cp_src[i])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ncopy = 3 * nbuf
         e0.record()
-        for _ in range(20):
-            cp_dst.copy_(cp_src)
+        for i in range(ncopy):
+            cp_dst[i % nbuf].copy_(cp_src[i % nbuf])
         e1.record()
         torch.cuda.synchronize(dev)
-        copy_ms = e0.elapsed_time(e1) / 20
+        copy_ms = e0.elapsed_time(e1) / ncopy
         copy_gbs = pf_bytes / (copy_ms * 1e-3) / 1e9 if copy_ms > 0 else 0.0
+        del cp_src, cp_dst
         roofline_pf = {"bound": "hbm", "kernel": "prefilter_kernel", "achieved": round(pf_bytes / (pf_ms * 1e-3) / 1e9, 2) if pf_ms > 0 else 0.0,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pf_bytes / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pf_ms > 0 else 0.0,
                        "kernel_ms": round(pf_ms, 4), "algorithmic_bytes_per_launch": pf_bytes,
