@@ -249,6 +249,12 @@ int sbm_fpga_bm_device(sbm_handle* h, int n, const void* d_xsbl_l, const void* d
 int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, const sbm_fpga_params* p,
                             void* d_disp, int sync);
 
+/* Host-memory form of sbm_fpga_compute_device for ONE pair, shaped like the frame Fpga::receiveDepthMap hands out
+ * (src/slam/src/core/FPGA.cpp:270-279: a dense height x width CV_16SC1 image): strided 8-bit rectified inputs, strided int16
+ * output, strides in bytes. Synchronous. */
+int sbm_fpga_compute(sbm_handle* h, const uint8_t* left, size_t left_stride, const uint8_t* right, size_t right_stride,
+                     const sbm_fpga_params* p, int16_t* disp, size_t disp_stride);
+
 /* ---- GFTT minimum-eigenvalue map of the PL ----------------------------------------------------------
  * The dense half of the reference's FPGA feature detector (src/dvp/rtl/gftt_sbl.v, gftt_box.v, gftt_eig.v, gftt_obuf.v):
  * per image a height*width uint16 map of (a + c) - sqrt((a - c)^2 + 4 b^2) over 3x3 boxes of the Sobel products, rows
@@ -258,6 +264,9 @@ int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void
  * d_img: n dense u8 images (the rectified left frames already on the device); d_eig: n*height*width uint16;
  * d_max: n uint32. width 3..1023, height 5..511 (the RTL's field widths). */
 int sbm_gftt_eig_device(sbm_handle* h, int n, const void* d_img, int width, int height, void* d_eig, void* d_max, int sync);
+/* Host-memory form for one image (what FPGA.cpp:283-291 builds: a CV_16UC1 map and the Max register). Synchronous. */
+int sbm_gftt_eig(sbm_handle* h, const uint8_t* img, size_t img_stride, int width, int height, uint16_t* eig, size_t eig_stride,
+                 uint32_t* max_out);
 
 /* The raw HIP stream (hipStream_t) as void*, so callers can order their own work behind ours (record an event on it
  * after sbm_compute_device(..., sync = 0)) or ours behind theirs (hipStreamWaitEvent on it before the call). Every entry

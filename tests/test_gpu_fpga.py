@@ -80,3 +80,15 @@ def test_limits_are_status_codes(pkg, bm):
         with pytest.raises(pkg.StereoBMError) as e:
             bm.fpga_bm(z, z, p)
         assert e.value.code == code
+
+
+def test_host_entry_points_of_the_pl_blocks(pkg, bm, oracle, golden):
+    """sbm_fpga_compute / sbm_gftt_eig on host images with a row stride (cv::Mat::step), the shapes FPGA.cpp:270-291 hands out."""
+    p = pkg.fpga_params_from_regs((480 << 16) + 640, 0x00150040, 0)
+    wide_l = np.zeros((480, 700), np.uint8); wide_l[:, :640] = golden["rect_l"]
+    wide_r = np.zeros((480, 700), np.uint8); wide_r[:, :640] = golden["rect_r"]
+    got = bm.fpga_compute_host(wide_l[:, :640], wide_r[:, :640], p)
+    assert np.array_equal(got, oracle.fpga_compute(golden["rect_l"], golden["rect_r"], 21, 64))
+    eig, mx = bm.gftt_eig_host(wide_l[:, :640])
+    ref, rmax = oracle.gftt_eig(golden["rect_l"])
+    assert np.array_equal(eig, ref) and mx == rmax

@@ -689,6 +689,50 @@ int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void
   return SBM_OK;
 }
 
+static int ensure_staging(sbm_handle* h, int n, int W, int H);
+
+// host-memory forms of the PL blocks for one frame: staged through the handle's device staging buffers (2-D copies
+// take care of the caller's strides)
+int sbm_fpga_compute(sbm_handle* h, const uint8_t* left, size_t left_stride, const uint8_t* right, size_t right_stride,
+                     const sbm_fpga_params* p, int16_t* disp, size_t disp_stride) {
+  if (!h || !left || !right || !p || !disp) return SBM_ERR_NULL;
+  int st = sbm_fpga_params_validate(p);
+  if (st != SBM_OK) return st;
+  const int W = p->width, H = p->height;
+  if (left_stride < (size_t)W || right_stride < (size_t)W || disp_stride < (size_t)W * 2) return SBM_ERR_SIZE;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  st = ensure_staging(h, 1, W, H);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, hipMemcpy2DAsync(h->st_l, W, left, left_stride, W, H, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->st_r, W, right, right_stride, W, H, hipMemcpyHostToDevice, h->stream));
+  st = sbm_fpga_compute_device(h, 1, h->st_l, h->st_r, p, h->st_d, 0);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, hipMemcpy2DAsync(disp, disp_stride, h->st_d, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SBM_OK;
+}
+
+int sbm_gftt_eig(sbm_handle* h, const uint8_t* img, size_t img_stride, int width, int height, uint16_t* eig, size_t eig_stride,
+                 uint32_t* max_out) {
+  if (!h || !img || !eig) return SBM_ERR_NULL;
+  if (width < 3 || height < 5 || width > 1023 || height > 511) return SBM_ERR_SIZE;
+  if (img_stride < (size_t)width || eig_stride < (size_t)width * 2) return SBM_ERR_SIZE;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  int st = ensure_staging(h, 1, width, height);
+  if (st != SBM_OK) return st;
+  // st_l: image, st_d: map, st_r: the Max word
+  HIPCHK(h, hipMemcpy2DAsync(h->st_l, width, img, img_stride, width, height, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, launch_gftt_eig(h->st_l, reinterpret_cast<uint16_t*>(h->st_d), reinterpret_cast<unsigned*>(h->st_r), 1, width, height, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(eig, eig_stride, h->st_d, (size_t)width * 2, (size_t)width * 2, height, hipMemcpyDeviceToHost, h->stream));
+  uint32_t mx = 0;
+  HIPCHK(h, hipMemcpyAsync(&mx, h->st_r, sizeof(mx), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (max_out) *max_out = mx;
+  return SBM_OK;
+}
+
 int sbm_gftt_eig_device(sbm_handle* h, int n, const void* d_img, int width, int height, void* d_eig, void* d_max, int sync) {
   if (!h || !d_img || !d_eig || !d_max) return SBM_ERR_NULL;
   if (n <= 0) return SBM_ERR_BATCH;

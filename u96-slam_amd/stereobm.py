@@ -152,6 +152,8 @@ def load_library():
     L.sbm_fpga_bm_device.argtypes = [vp, ci, vp, vp, fp, vp, ci]
     L.sbm_fpga_compute_device.argtypes = [vp, ci, vp, vp, fp, vp, ci]
     L.sbm_gftt_eig_device.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci]
+    L.sbm_fpga_compute.argtypes = [vp, vp, sz, vp, sz, fp, vp, sz]
+    L.sbm_gftt_eig.argtypes = [vp, vp, sz, ci, ci, vp, sz, ctypes.POINTER(u32)]
     L.sbm_stream.argtypes = [vp]
     L.sbm_stream.restype = vp
     L.sbm_strerror.argtypes = [ci]
@@ -428,6 +430,27 @@ class StereoBM:
     def fpga_compute(self, left, right, params):
         """xsbl2.v prefilter + RTL block matcher on rectified frames: the PL pipeline behind Fpga::receiveDepthMap."""
         return self._fpga(self._L.sbm_fpga_compute_device, left, right, params)
+
+    def fpga_compute_host(self, left, right, params):
+        """numpy uint8 (H,W) rectified pair -> numpy int16 (H,W): the frame Fpga::receiveDepthMap would hand out."""
+        if left.shape != right.shape or left.dtype != np.uint8 or right.dtype != np.uint8 or left.ndim != 2:
+            raise StereoBMError(-2, "both inputs must be (H,W) uint8 arrays of the same shape")
+        if left.strides[1] != 1 or right.strides[1] != 1 or left.strides[0] < left.shape[1] or right.strides[0] < right.shape[1]:
+            raise StereoBMError(-2, "rows must be dense with a positive row stride")
+        out = np.empty(left.shape, np.int16)
+        _check(self._L.sbm_fpga_compute(self._h, left.ctypes.data, left.strides[0], right.ctypes.data, right.strides[0],
+                                        ctypes.byref(params), out.ctypes.data, out.strides[0]), self._h)
+        return out
+
+    def gftt_eig_host(self, img):
+        """numpy uint8 (H,W) -> (numpy uint16 map, Max register value), as FPGA.cpp:283-291 assembles them."""
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            raise StereoBMError(-2, "image must be an (H,W) uint8 array with dense rows")
+        out = np.empty(img.shape, np.uint16)
+        mx = ctypes.c_uint32()
+        _check(self._L.sbm_gftt_eig(self._h, img.ctypes.data, img.strides[0], img.shape[1], img.shape[0], out.ctypes.data,
+                                    out.strides[0], ctypes.byref(mx)), self._h)
+        return out, int(mx.value)
 
     def gftt_eig(self, img):
         """PL GFTT min-eigenvalue map of torch CUDA uint8 frames (n,H,W) or (H,W): (int16-viewed uint16 map as torch.int32,
