@@ -526,3 +526,20 @@ def test_output_buffer_validation(pkg, torch_cuda):
     d = bm.compute_device(L, L, sync=False)      # async: the wrapper keeps the buffers alive until synchronize()
     bm.synchronize()
     assert d.shape == L.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lists", ["1", "0"])
+def test_speckle_with_one_run_per_pixel(pkg, oracle, lists, monkeypatch):
+    """speckleRange 0 on a noisy map: adjacent valid pixels rarely agree, so nearly every pixel is its own run -- the
+    worst case for the compact run-head lists of the speckle filter (up to W heads per row), in both kernel variants."""
+    monkeypatch.setenv("SBM_SPECKLE_LISTS", lists)
+    rng = np.random.default_rng(42)
+    L = rng.integers(0, 256, (3, 96, 400), dtype=np.uint8)      # no correlation between the images: disparities are noise
+    R = rng.integers(0, 256, (3, 96, 400), dtype=np.uint8)
+    kw = dict(num_disparities=64, block_size=5, texture_threshold=0, uniqueness_ratio=0, speckle_window_size=3, speckle_range=0,
+              disp12_max_diff=-1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+    valid = eng["disp"] >= 0
+    assert valid.mean() > 0.01 and (eng["pre_lr"] >= 0).mean() > 0.3   # the filter had work and left something to compare

@@ -56,9 +56,10 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
                           int disp12_max_diff, hipStream_t s);
 
-// cv filterSpeckles as parallel connected components (union-find). labels/counts: n*H*W int32 scratch each.
-hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
-                          hipStream_t s);
+// cv filterSpeckles as parallel connected components (union-find). labels/counts: n*H*W int32 scratch each; heads:
+// n*H*W uint32 and nheads: n*H int32 (compact per-row run-head lists; may be null -> row-walking kernels).
+hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, const Geom& g,
+                          int max_size, int max_diff, hipStream_t s);
 
 // Stand-alone prefilter of dense images (either flavour) and the rectifier in front of it (sbm_rectify.hip).
 hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, int W, int H, int rtl, int cap,

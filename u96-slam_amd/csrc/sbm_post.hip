@@ -3,6 +3,8 @@
 // Device counterparts of validateDisparity / filterSpeckles (OpenCV calib3d stereosgbm.cpp), switched on by
 // setDisp12MaxDiff(1), setSpeckleWindowSize(50), setSpeckleRange(32) at src/slam/src/core/main.cpp:210-212.
 // Neither has an FPGA twin in the reference.
+#include <stdlib.h>
+
 #include "sbm_common.h"
 
 namespace sbm {
@@ -301,14 +303,19 @@ __device__ __forceinline__ void spk_load_group(const int16_t* d, int cb0, int W,
   (void)lane;
 
 // grid: (ceil(H/4), n), block 256 = 4 wavefronts = 4 rows
+// With `heads` != nullptr the row's run heads are also appended, in column order, to a compact list
+// (heads[row][k] = column | run length << 16, nheads[row]) so that the count and apply kernels need not walk the rows again.
 __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
-                                                            int* __restrict__ counts, int W, int H, int newval,
+                                                            int* __restrict__ counts, unsigned* __restrict__ heads,
+                                                            int* __restrict__ nheads, int HS, int W, int H, int newval,
                                                             int maxdiff) {
   SPK_ROW_SETUP
   if (y >= H) return;
   const int16_t* d = disp + plane_off + (size_t)y * W;
   int* L = labels + plane_off + (size_t)y * W;
   int* C = counts + plane_off + (size_t)y * W;
+  unsigned* hl = heads ? heads + ((size_t)blockIdx.y * H + y) * HS : nullptr;
+  int nh = 0, open_k = -1;   // uniform: heads listed so far, list slot of the run that is still open
   // every head learns the distance to the next boundary (head, invalid pixel or row end). A run that leaves its chunk
   // stays "open" (uniform state) and is closed by the first boundary of a later chunk.
   RowWalk rw;
@@ -324,22 +331,35 @@ __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __rest
       rw.step(vs[g], cb, lane, newval, maxdiff);
       const unsigned long long hm = rw.head, bm = hm | ~rw.valid;   // lanes beyond W are invalid = boundary
       if (open_start >= 0 && bm) {
-        if (lane == 0) C[open_start] = cb + (__ffsll((long long)bm) - 1) - open_start;
+        if (lane == 0) {
+          const int len = cb + (__ffsll((long long)bm) - 1) - open_start;
+          C[open_start] = len;
+          if (hl) hl[open_k] = (unsigned)open_start | ((unsigned)len << 16);
+        }
         open_start = -1;
       }
       if (hm) {                                                      // uniform: most chunks hold no run head
         if ((hm >> lane) & 1ull) {
           const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
           L[cb + lane] = y * W + cb + lane;
-          if (above) C[cb + lane] = __ffsll((long long)above);
+          const int len = above ? __ffsll((long long)above) : 0;    // 0: closed by a later chunk (or the row end)
+          if (above) C[cb + lane] = len;
+          if (hl) hl[nh + __popcll(hm & ((1ull << lane) - 1ull))] = (unsigned)(cb + lane) | ((unsigned)len << 16);
         }
         const int hb = 63 - __clzll((long long)hm);                  // the last head stays open if nothing bounds it
-        if (hb == 63 || (bm >> (hb + 1)) == 0ull) open_start = cb + hb;
+        nh += __popcll(hm);
+        if (hb == 63 || (bm >> (hb + 1)) == 0ull) { open_start = cb + hb; open_k = nh - 1; }
       }
       rw.next(vs[g]);
     }
   }
-  if (open_start >= 0 && lane == 0) C[open_start] = W - open_start;
+  if (lane == 0) {
+    if (open_start >= 0) {
+      C[open_start] = W - open_start;
+      if (hl) hl[open_k] = (unsigned)open_start | ((unsigned)(W - open_start) << 16);
+    }
+    if (nheads) nheads[(size_t)blockIdx.y * H + y] = nh;
+  }
 }
 
 // The row walk only COLLECTS the contacts (pairs of run heads) into a wavefront-private LDS list; the unions -- chains
@@ -508,15 +528,70 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
   }
 }
 
-hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, const Geom& g, int max_size, int max_diff,
-                          hipStream_t s) {
+// ---- list-driven count / apply: one wavefront per row, one lane per run head of the row's compact list --------------------
+__global__ void __launch_bounds__(256) speckle_count_list_kernel(int* __restrict__ labels, int* __restrict__ counts,
+                                                                  const unsigned* __restrict__ heads,
+                                                                  const int* __restrict__ nheads, int HS, int W, int H,
+                                                                  int maxsize) {
+  SPK_ROW_SETUP
+  if (y >= H) return;
+  int* L = labels + plane_off;
+  int* C = counts + plane_off;
+  const size_t row = (size_t)blockIdx.y * H + y;
+  const unsigned* hl = heads + row * HS;
+  const int nh = nheads[row];
+  for (int i = lane; i < nh; i += 64) {
+    const unsigned e = hl[i];
+    const int self = y * W + (int)(e & 0xffffu);
+    const int r = uf_root_final(L, self);
+    if (r != self) {
+      L[self] = r;   // parents are final: point straight at the root so the apply kernel's lookup is one step
+      if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, (int)(e >> 16));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __restrict__ disp, const int* __restrict__ labels,
+                                                                  const int* __restrict__ counts,
+                                                                  const unsigned* __restrict__ heads,
+                                                                  const int* __restrict__ nheads, int HS, int W, int H,
+                                                                  int newval, int maxsize) {
+  SPK_ROW_SETUP
+  if (y >= H) return;
+  int16_t* d = disp + plane_off + (size_t)y * W;
+  const int* L = labels + plane_off;
+  const int* C = counts + plane_off;
+  const size_t row = (size_t)blockIdx.y * H + y;
+  const unsigned* hl = heads + row * HS;
+  const int nh = nheads[row];
+  for (int i = lane; i < nh; i += 64) {
+    const unsigned e = hl[i];
+    const int x = (int)(e & 0xffffu), len = (int)(e >> 16);
+    if (C[uf_root_final(L, y * W + x)] <= maxsize)          // a speckle: its runs are at most maxsize long
+      for (int j = 0; j < len; j++) d[x + j] = (int16_t)newval;
+  }
+}
+
+hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, const Geom& g,
+                          int max_size, int max_diff, hipStream_t s) {
   dim3 grid((g.H + 3) / 4, g.n);
-  hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff);
+  const int HS = g.W;   // adjacent valid pixels further apart than maxDiff are separate runs: up to W runs per row
+  // compact head lists (column and run length packed in 16 bits each); SBM_SPECKLE_LISTS=0 forces the row-walking kernels
+  const char* e = getenv("SBM_SPECKLE_LISTS");
+  const bool lists = heads && nheads && g.W <= 65535 && !(e && atoi(e) == 0);
+  hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, lists ? heads : nullptr,
+                     lists ? nheads : nullptr, HS, g.W, g.H, g.filtered, max_diff);
   hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
-  hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
-                     max_size);
-  hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
-                     max_size);
+  if (lists) {
+    hipLaunchKernelGGL(speckle_count_list_kernel, grid, dim3(256), 0, s, labels, counts, heads, nheads, HS, g.W, g.H, max_size);
+    hipLaunchKernelGGL(speckle_apply_list_kernel, grid, dim3(256), 0, s, disp, labels, counts, heads, nheads, HS, g.W, g.H,
+                       g.filtered, max_size);
+  } else {
+    hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
+                       max_size);
+    hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
+                       max_size);
+  }
   return hipGetLastError();
 }
 
