@@ -156,23 +156,17 @@ __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int x = x0 + i;
-      int d = dv[k][i];
-      if (x < a.col0 || x >= a.col1) {
-        d = INV;
-      } else if (d != INV && x >= minX1 && x < maxX1) {
-        const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
-        bool bad_a = false, bad_b = false;
-        if (xa >= 0 && xa < a.W) {
-          const unsigned kk = keys[xa];
-          if (kk != 0xffffffffu) bad_a = abs((int)srow[kk & 0xffffu] - d) > a.tol;
-        }
-        if (xb >= 0 && xb < a.W) {
-          const unsigned kk = keys[xb];
-          if (kk != 0xffffffffu) bad_b = abs((int)srow[kk & 0xffffu] - d) > a.tol;
-        }
-        if (bad_a && bad_b) d = INV;
-      }
-      res[i] = (short)d;
+      // branch-free: the look-ups read slot 0 when they do not apply (four nested conditionals per pixel cost more in
+      // exec-mask bookkeeping than the two spare LDS reads)
+      const int d = dv[k][i];
+      const bool live = d != INV && x >= minX1 && x < maxX1;
+      const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
+      const bool ia = live && (unsigned)xa < (unsigned)a.W, ib = live && (unsigned)xb < (unsigned)a.W;
+      const unsigned ka = keys[ia ? xa : 0], kb = keys[ib ? xb : 0];
+      const bool ha = ia && ka != 0xffffffffu, hb = ib && kb != 0xffffffffu;
+      const int da = srow[ha ? (ka & 0xffffu) : 0u], db = srow[hb ? (kb & 0xffffu) : 0u];
+      const bool bad = ha && hb && abs(da - d) > a.tol && abs(db - d) > a.tol;
+      res[i] = (short)((x < a.col0 || x >= a.col1 || bad) ? INV : d);
     }
     if (x0 + 4 <= a.W) {
       __builtin_memcpy(out + x0, res, 8);
