@@ -131,14 +131,12 @@ int sbm_synchronize(sbm_handle* h);
 int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
 
 /* Per-stage device time in ms, measured with HIP events recorded on the handle's stream around each stage.
- * enabled = 1: every sbm_compute_device call synchronises, stages run strictly one after the other (no sub-batch
- *              pipeline) and sbm_get_profile returns the LAST call's times;
+ * enabled = 1: every sbm_compute_device call synchronises and sbm_get_profile returns the LAST call's times;
  * enabled = 2: events are recorded without synchronising (use inside a timed region) and sbm_get_profile
  *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
  * names: "prefilter", "sad" (fast SAD/WTA kernel; every SAD launch of the call when it is pipelined), "border" (what
  * is left of the border-column kernel after the interior kernel has finished; the generic kernel when the fast path
- * is off), "lrcheck", "speckle", "total". (With the experimental sub-batch pipeline, SBM_SUBBATCH > 1, "border" and
- * "lrcheck" read 0 and "speckle" is the post-filter tail left after the last SAD launch.) */
+ * is off), "lrcheck", "speckle", "total". */
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
 

@@ -21,13 +21,7 @@ struct sbm_handle {
   int device;
   hipStream_t stream;
   hipStream_t stream2;   // side stream: the latency-bound border kernel overlaps the VALU-bound SAD kernel
-  hipStream_t stream3;   // post-filter stream of the sub-batch pipeline: LR check + speckle of sub-batch k run while the
-                         // SAD kernel of sub-batch k+1 owns the VALUs
-  hipStream_t stream4;   // second SAD stream (optional): consecutive SAD launches alternate so one ramps up while the
-                         // previous one drains
   hipEvent_t ev_fork, ev_join;
-  static constexpr int kMaxSub = 8;
-  hipEvent_t ev_sad[kMaxSub], ev_bord[kMaxSub], ev_post, ev_sad4;
   int last_hip;
   // scratch, sized for (cap_n, cap_W, cap_H, cap pitch)
   int cap_n, cap_W, cap_H, cap_pitch;
@@ -229,16 +223,8 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
   int lo = 0, hi = 0;
   ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
   ok = ok && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) == hipSuccess;
-  ok = ok && hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, hi) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_post, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_sad4, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < sbm_handle::kMaxSub; i++) {
-    ok = hipEventCreateWithFlags(&h->ev_sad[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_bord[i], hipEventDisableTiming) == hipSuccess;
-  }
   if (!ok) {
     destroy_now(h);
     return SBM_ERR_HIP;
@@ -253,8 +239,6 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
 static void sync_all_streams(sbm_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream2) hipStreamSynchronize(h->stream2);
-  if (h->stream3) hipStreamSynchronize(h->stream3);
-  if (h->stream4) hipStreamSynchronize(h->stream4);
   if (h->stream_in) hipStreamSynchronize(h->stream_in);
   if (h->stream_out) hipStreamSynchronize(h->stream_out);
 }
@@ -297,16 +281,8 @@ static void destroy_now(sbm_handle* h) {
   }
   if (h->stream_in) hipStreamDestroy(h->stream_in);
   if (h->stream_out) hipStreamDestroy(h->stream_out);
-  for (int i = 0; i < sbm_handle::kMaxSub; i++) {
-    if (h->ev_sad[i]) hipEventDestroy(h->ev_sad[i]);
-    if (h->ev_bord[i]) hipEventDestroy(h->ev_bord[i]);
-  }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  if (h->ev_post) hipEventDestroy(h->ev_post);
-  if (h->ev_sad4) hipEventDestroy(h->ev_sad4);
-  if (h->stream4) hipStreamDestroy(h->stream4);
-  if (h->stream3) hipStreamDestroy(h->stream3);
   if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -464,27 +440,14 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   // columns left and right of the fast range: clamped windows. They only matter if they can influence the output:
   // through the LR check or when inside the valid ROI.
   const bool borders_visible = g.want_cost || g.col0 < g.lofs + fa || g.col1 > g.lofs + fb;
-  static const int side_env = [] { const char* e = getenv("SBM_SIDE"); return e ? atoi(e) : 1; }();
-  const bool side = fast && borders_visible && side_env;   // border columns on the side stream, under the interior kernel
-  const bool border_inline = fast && borders_visible && !side_env;
-
-  // Sub-batch pipeline (OFF by default, SBM_SUBBATCH=k turns it on): SAD of sub-batch k+1 on the main stream while LR +
-  // speckle of sub-batch k run on a second high-priority stream. Measured on MI355X (round 2, KITTI 64 pairs,
-  // profiles/r02_subbatch_pipeline.md): 1.47 ms -> 1.54 (k=2) / 1.73 (k=4). The SAD kernel holds 4 wavefronts x 126
-  // VGPRs on every SIMD, so a post-filter wavefront can only start where a SAD workgroup has just retired: the kernel
-  // trace shows LR(k) starting with SAD(k+1) and finishing with it, and the smaller SAD launches lose more to their own
-  // tails than the overlap gives back. Kept for re-measurement when the SAD kernel's occupancy changes.
-  int nsub = 1;
-  {
-    static const int sub_env = [] { const char* e = getenv("SBM_SUBBATCH"); return e ? atoi(e) : 1; }();
-    const bool has_post = g.want_cost || speckle;
-    if (fast && has_post && h->profiling != 1 && sub_env > 1)
-      nsub = std::max(1, std::min(std::min(sub_env, (int)sbm_handle::kMaxSub), n));
-  }
-  static const int sad_streams = [] { const char* e = getenv("SBM_SAD_STREAMS"); return e ? atoi(e) : 1; }();
+  const bool side = fast && borders_visible;   // border columns on the side stream, under the interior kernel
+  // Stages run one after the other on the main stream. Overlapping LR + speckle of one sub-batch with the SAD kernel of
+  // the next was built and measured in round 2 (profiles/r02_subbatch_pipeline.md; the code is in the history at commit
+  // "Engine: device guard ..."): 1.47 ms -> 1.54 / 1.73 ms with 2 / 4 sub-batches, because four 126-VGPR wavefronts per
+  // SIMD leave no registers for a guest wavefront -- the post-filters only overlap once the SAD kernel runs at 3
+  // wavefronts per SIMD, which costs it 27 %.
   const uint8_t* dl = (const uint8_t*)d_left;
   const uint8_t* dr = (const uint8_t*)d_right;
-  const size_t pix1 = (size_t)width * height;
 
   mark(h, 0);
   if (any_rows) {
@@ -496,75 +459,31 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
     }
   }
   mark(h, 1);
-  if (nsub == 1) {
-    if (any_rows) {
-      if (side) {
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream2));
-        HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
-      }
-      if (fast) {
-        int xa = 0, xb = 0;
-        if (border_inline) HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream));
-        HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
-      } else {
-        HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
-      }
-      mark(h, 2);
-      if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    } else {
-      mark(h, 2);
+  if (any_rows) {
+    if (side) {
+      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+      HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream2));
+      HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
     }
-    mark(h, 3);
-    HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
-    mark(h, 4);
-    if (speckle)
-      HIPCHK(h, launch_speckle(out, h->labels, h->counts, h->spk_heads, h->spk_nheads, g, p.speckle_window_size, p.speckle_range,
-                               h->stream));
-    mark(h, 5);
-  } else {
-    // (nsub > 1 implies fast, hence any_rows)
-    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));                 // prefiltered planes are ready
-    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    const bool two = sad_streams > 1;
-    if (two) HIPCHK(h, hipStreamWaitEvent(h->stream4, h->ev_fork, 0));
-    const size_t cost_el = g.cost16 ? sizeof(uint16_t) : sizeof(int32_t);
-    for (int k = 0; k < nsub; k++) {
-      const int i0 = (int)((long)n * k / nsub), i1 = (int)((long)n * (k + 1) / nsub);
-      Geom gk = g;
-      gk.n = i1 - i0;
-      const uint8_t* pfl = h->pf_l + (size_t)i0 * g.plane;
-      const uint8_t* pfr = h->pf_r + (size_t)i0 * g.plane;
-      int16_t* dpre = h->disp_pre + i0 * pix1;
-      int32_t* costk = h->cost ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(h->cost) + i0 * pix1 * cost_el) : nullptr;
-      if (side) {
-        HIPCHK(h, launch_sad_border(pfl, pfr, dpre, costk, gk, fa, fb, h->stream2));
-        HIPCHK(h, hipEventRecord(h->ev_bord[k], h->stream2));
-      }
-      hipStream_t ss = (two && (k & 1)) ? h->stream4 : h->stream;
+    if (fast) {
       int xa = 0, xb = 0;
-      HIPCHK(h, launch_sad_fast(pfl, pfr, dpre, costk, gk, &xa, &xb, ss));
-      HIPCHK(h, hipEventRecord(h->ev_sad[k], ss));
-      HIPCHK(h, hipStreamWaitEvent(h->stream3, h->ev_sad[k], 0));
-      if (side) HIPCHK(h, hipStreamWaitEvent(h->stream3, h->ev_bord[k], 0));
-      HIPCHK(h, launch_lrcheck(dpre, costk, out + i0 * pix1, gk, p.disp12_max_diff, h->stream3));
-      if (speckle)
-        HIPCHK(h, launch_speckle(out + i0 * pix1, h->labels + i0 * pix1, h->counts + i0 * pix1,
-                                 h->spk_heads + i0 * pix1, h->spk_nheads + (size_t)i0 * height, gk,
-                                 p.speckle_window_size, p.speckle_range, h->stream3));
+      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
+    } else {
+      HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
     }
-    if (two) {
-      HIPCHK(h, hipEventRecord(h->ev_sad4, h->stream4));
-      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sad4, 0));
-    }
-    mark(h, 2);   // "sad" = all SAD launches of the call (post-filters of earlier sub-batches run underneath)
-    mark(h, 3);
-    mark(h, 4);
-    HIPCHK(h, hipEventRecord(h->ev_post, h->stream3));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_post, 0));
-    mark(h, 5);   // "speckle" = the exposed tail: border/LR/speckle work still running when the last SAD launch ends
+    mark(h, 2);
+    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  } else {
+    mark(h, 2);
   }
+  mark(h, 3);
+  HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
+  mark(h, 4);
+  if (speckle)
+    HIPCHK(h, launch_speckle(out, h->labels, h->counts, h->spk_heads, h->spk_nheads, g, p.speckle_window_size, p.speckle_range,
+                             h->stream));
+  mark(h, 5);
   if (h->profiling) h->calls++;
   if (sync || h->profiling == 1) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
