@@ -529,11 +529,41 @@ def test_output_buffer_validation(pkg, torch_cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lists", ["1", "0"])
-def test_speckle_with_one_run_per_pixel(pkg, oracle, lists, monkeypatch):
+@pytest.mark.parametrize("band", ["0", "2", "4", "8"])
+@pytest.mark.parametrize("shape", [(37, 70, 1), (130, 300, 2), (64, 257, 3), (375, 1242, 2), (201, 515, 40)])
+def test_speckle_band_walk_variants(pkg, oracle, band, shape, monkeypatch):
+    """The speckle filter's band walk (runs + merge of 2/4/8 rows in one wavefront, seam contacts unioned by a second
+    kernel) against the oracle: heights that are not multiples of the band, widths that are not multiples of a chunk or a
+    load group, components that cross many seams, and a batch large enough for every automatic band choice."""
+    from u96_slam_amd import synth
+
+    monkeypatch.setenv("SBM_SPECKLE_BAND", band)
+    H, W, n = shape
+    nd = 32 if W < 400 else 64
+    L, R = synth.make_batch(11, n, W, H, nd)
+    kw = dict(num_disparities=nd, block_size=9, texture_threshold=10, uniqueness_ratio=5, speckle_window_size=60,
+              speckle_range=16, disp12_max_diff=1)
+    if n > 8:   # oracle on a few pairs of the batch only
+        bm = pkg.StereoBM.create(nd, 9)
+        bm.setTextureThreshold(10); bm.setUniquenessRatio(5); bm.setSpeckleWindowSize(60); bm.setSpeckleRange(16)
+        bm.setDisp12MaxDiff(1)
+        disp = bm.compute(L, R)
+        p = oracle.make_params(**kw)
+        for i in (0, n // 2, n - 1):
+            assert np.array_equal(disp[i], oracle.compute(p, L[i], R[i])), f"pair {i}"
+        return
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+    assert (eng["disp"] != eng["pre_lr"]).any()   # the post-filters removed something
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lists,band", [("1", "-1"), ("1", "0"), ("1", "2"), ("1", "4"), ("1", "8"), ("0", "-1")])
+def test_speckle_with_one_run_per_pixel(pkg, oracle, lists, band, monkeypatch):
     """speckleRange 0 on a noisy map: adjacent valid pixels rarely agree, so nearly every pixel is its own run -- the
-    worst case for the compact run-head lists of the speckle filter (up to W heads per row), in both kernel variants."""
+    worst case for the compact run-head lists of the speckle filter (up to W heads per row), in every kernel variant."""
     monkeypatch.setenv("SBM_SPECKLE_LISTS", lists)
+    monkeypatch.setenv("SBM_SPECKLE_BAND", band)   # band walk (2/4/8 rows per wavefront), 0 = separate runs + merge kernels
     rng = np.random.default_rng(42)
     L = rng.integers(0, 256, (3, 96, 400), dtype=np.uint8)      # no correlation between the images: disparities are noise
     R = rng.integers(0, 256, (3, 96, 400), dtype=np.uint8)

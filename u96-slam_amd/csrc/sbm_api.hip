@@ -30,6 +30,8 @@ struct sbm_handle {
   int32_t *cost, *labels, *counts;
   uint32_t* spk_heads;   // compact per-row run-head lists of the speckle filter: cap_n * H * W entries
   int32_t* spk_nheads;   // cap_n * H
+  uint32_t* spk_seam;    // contacts across band seams (band walk of the speckle filter): cap_n * ceil(H/2) * W entries
+  int32_t* spk_nseam;    // cap_n * ceil(H/2)
   uint16_t* vsum;      // column sums of PREFILTER_NORMALIZED_RESPONSE (2 * cap_n * W * H), allocated on first use
   // FPGA-flavour matcher scratch (allocated on first use, sized for fp_n pairs of fp_W x fp_H)
   int fp_n, fp_W, fp_H;
@@ -138,8 +140,8 @@ int sbm_version(void) { return SBM_VERSION_MAJOR * 1000 + SBM_VERSION_MINOR; }
 
 static void free_scratch(sbm_handle* h) {
   hipFree(h->pf_l); hipFree(h->pf_r); hipFree(h->disp_pre); hipFree(h->cost); hipFree(h->labels); hipFree(h->counts);
-  hipFree(h->spk_heads); hipFree(h->spk_nheads);
-  h->spk_heads = nullptr; h->spk_nheads = nullptr;
+  hipFree(h->spk_heads); hipFree(h->spk_nheads); hipFree(h->spk_seam); hipFree(h->spk_nseam);
+  h->spk_heads = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr; h->spk_nseam = nullptr;
   hipFree(h->vsum);
   h->vsum = nullptr;
   h->pf_l = h->pf_r = nullptr; h->disp_pre = nullptr; h->cost = h->labels = h->counts = nullptr;
@@ -172,7 +174,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   const size_t npix = (size_t)h->cap_n * h->cap_W * h->cap_H, plane = (size_t)h->cap_n * h->cap_pitch * h->cap_H;
   size_t b = 2 * plane + npix * 2;
   if (h->cost) b += npix * 4;
-  if (h->labels) b += npix * 12 + (size_t)h->cap_n * h->cap_H * 4;
+  if (h->labels) b += npix * 14 + (size_t)h->cap_n * h->cap_H * 6;   // labels, counts, head lists, seam lists
   if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
   b += (size_t)h->fp_n * h->fp_W * h->fp_H * 12 + (size_t)2 * h->fp_n * (h->fp_W + 191) * h->fp_H;
@@ -357,6 +359,9 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
     HIPCHK(h, hipMalloc((void**)&h->counts, npix * sizeof(int32_t)));
     HIPCHK(h, hipMalloc((void**)&h->spk_heads, npix * sizeof(uint32_t)));
     HIPCHK(h, hipMalloc((void**)&h->spk_nheads, (size_t)h->cap_n * H * sizeof(int32_t)));
+    const size_t seams = (size_t)h->cap_n * ((H + 1) / 2);
+    HIPCHK(h, hipMalloc((void**)&h->spk_seam, seams * W * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc((void**)&h->spk_nseam, seams * sizeof(int32_t)));
   }
   return SBM_OK;
 }
@@ -481,7 +486,7 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
   mark(h, 4);
   if (speckle)
-    HIPCHK(h, launch_speckle(out, h->labels, h->counts, h->spk_heads, h->spk_nheads, g, p.speckle_window_size, p.speckle_range,
+    HIPCHK(h, launch_speckle(out, h->labels, h->counts, h->spk_heads, h->spk_nheads, h->spk_seam, h->spk_nseam, g, p.speckle_window_size, p.speckle_range,
                              h->stream));
   mark(h, 5);
   if (h->profiling) h->calls++;

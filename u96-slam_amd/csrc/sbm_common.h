@@ -58,7 +58,8 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 
 // cv filterSpeckles as parallel connected components (union-find). labels/counts: n*H*W int32 scratch each; heads:
 // n*H*W uint32 and nheads: n*H int32 (compact per-row run-head lists; may be null -> row-walking kernels).
-hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, const Geom& g,
+hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, uint32_t* seam,
+                          int32_t* nseam, const Geom& g,
                           int max_size, int max_diff, hipStream_t s);
 
 // Stand-alone prefilter of dense images (either flavour) and the rectifier in front of it (sbm_rectify.hip).

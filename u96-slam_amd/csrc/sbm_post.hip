@@ -253,12 +253,25 @@ __device__ __forceinline__ int uf_root_final(const int* L, int i) {
 // pixels, run heads) that cost a handful of compares plus scalar mask algebra; the per-lane "column where my run
 // starts" -- the expensive part -- is only computed on demand (start()), i.e. in the few chunks where a kernel has
 // something to do (a vertical contact, a run to erase). State carried across chunks: prev_last (value left of the
-// chunk), prev_valid, carry (run start of the pixel left of the chunk, -1 if it is invalid).
+// chunk), lvalid (that pixel is valid), carry (run start of the pixel left of the chunk, -1 if it is invalid).
+// lane predicate / prefix count of a wavefront-uniform mask without per-lane 64-bit arithmetic (exec := mask; v_mbcnt)
+__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+// element idx of a wavefront-uniform array through a 32-bit byte offset (scalar base + vector offset addressing); the
+// callers guarantee idx * sizeof(T) < 4 GiB
+template <typename T>
+__device__ __forceinline__ T* at32(T* base, unsigned idx) {
+  return (T*)((const char*)base + (size_t)(idx * (unsigned)sizeof(T)));
+}
+
 struct RowWalk {
   int prev_last, carry, cb;
-  bool prev_valid;
+  unsigned lvalid;                  // 1 when the pixel left of the chunk is valid (kept as a shifted mask bit: a bool would
+                                    // be widened through a VALU select)
   unsigned long long valid, head;   // uniform
-  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; prev_valid = false; }
+  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; lvalid = 0; }
   // masks of the chunk at column cb_ (lanes beyond the row hold newval = invalid)
   __device__ __forceinline__ void step(int v, int cb_, int lane, int newval, int maxdiff) {
     cb = cb_;
@@ -267,19 +280,19 @@ struct RowWalk {
     const int pv = __builtin_amdgcn_update_dpp(prev_last, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     valid = __ballot(v != newval);
     const unsigned long long closem = __ballot(abs(v - pv) <= maxdiff);
-    const unsigned long long pvalid = (valid << 1) | (prev_valid ? 1ull : 0ull);
+    const unsigned long long pvalid = (valid << 1) | lvalid;
     head = valid & ~(pvalid & closem);
   }
   // column where the lane's run starts (meaningful for valid lanes)
   __device__ __forceinline__ int start(int lane) const {
-    const unsigned long long m = head & ((2ull << lane) - 1ull);
-    return m ? cb + (63 - __clzll((long long)m)) : carry;
+    const unsigned long long t = head << (63 - lane);   // heads at or below this lane, the nearest one in bit 63
+    return t ? cb + lane - __clzll((long long)t) : carry;
   }
   // advance the carried state to the next chunk (uniform arithmetic only)
   __device__ __forceinline__ void next(int v) {
     const bool v63 = (valid >> 63) & 1ull;
     carry = v63 ? (head ? cb + (63 - __clzll((long long)head)) : carry) : -1;
-    prev_valid = v63;
+    lvalid = (unsigned)(valid >> 63);
     prev_last = __builtin_amdgcn_readlane(v, 63);
   }
   // bit position (0..63) of the head of the run that contains pixel 63 of this chunk, -1 if that run started earlier
@@ -299,7 +312,8 @@ __device__ __forceinline__ void spk_load_group(const int16_t* d, int cb0, int W,
 
 #define SPK_ROW_SETUP                                          \
   const int lane = threadIdx.x & 63;                           \
-  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);           \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* uniform: keeps row pointers in SGPRs */ \
+  const int y = blockIdx.x * 4 + wave;                         \
   const size_t plane_off = (size_t)blockIdx.y * W * H;         \
   (void)lane;
 
@@ -375,7 +389,7 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
   const int16_t* du = disp + plane_off + (size_t)y * W;
   const int16_t* dd = du + W;
   int* L = labels + plane_off;
-  int2* const list = contact_lds[threadIdx.x >> 6];
+  int2* const list = contact_lds[wave];
   int count = 0;   // uniform
   auto flush = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -420,6 +434,166 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
   if (count) flush();
 }
 
+// ---- band walk: runs + merge in one pass ---------------------------------------------------------------------------------
+// One wavefront owns G consecutive rows (a band) and walks them together, chunk by chunk, with the band's next row as a
+// look-ahead: every row is stepped once per chunk instead of three times (once by `runs`, twice by `merge` as the upper and
+// the lower row of a pair), which is what these issue-bound kernels pay for. Contacts between two rows of the band are
+// unioned by the band's own wavefront (nobody else touches the band's labels in this kernel, so the labels written a few
+// instructions earlier are simply ordered by a vmcnt wait); contacts across the seam to the next band are appended to a
+// per-band list (upper head column | lower head column << 16) and unioned by speckle_seam_kernel once every band is done.
+constexpr int SPK_BG = 4;   // chunks loaded up front per row
+
+template <int G>
+__global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
+                                                            int* __restrict__ counts, unsigned* __restrict__ heads,
+                                                            int* __restrict__ nheads, unsigned* __restrict__ seam,
+                                                            int* __restrict__ nseam, int HS, int W, int H, int newval,
+                                                            int maxdiff) {
+  constexpr int SPK_BCAP = 128 * (G - 1) < 256 ? 256 : 128 * (G - 1);   // in-band contacts buffered per wavefront
+  __shared__ int2 contact_lds[4][SPK_BCAP];
+  const int lane = threadIdx.x & 63;
+  const int nbands = (H + G - 1) / G;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: keeps row pointers and counters in SGPRs
+  const int band = blockIdx.x * 4 + wave;
+  if (band >= nbands) return;
+  const int y0 = band * G;
+  const size_t plane_off = (size_t)blockIdx.y * W * H;
+  const int16_t* d = disp + plane_off;
+  int* L = labels + plane_off;
+  int* C = counts + plane_off;
+  int2* const list = contact_lds[wave];
+  unsigned* const sl = seam + ((size_t)blockIdx.y * nbands + band) * HS;
+  int count = 0, nsm = 0;   // uniform: buffered in-band contacts, seam contacts listed so far
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // label stores of this wavefront have left before the unions start
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < count; i += 64) {
+      const int2 c = list[i];
+      uf_union(L, c.x, c.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    count = 0;
+  };
+  RowWalk rw[G + 1];
+  int nh[G], open_start[G];   // heads listed so far; start of the run still open (its list slot is nh - 1)
+  unsigned prev_cd[G];        // vertical contact between rows r and r+1 at the pixel left of the chunk (0 / 1)
+#pragma unroll
+  for (int r = 0; r <= G; r++) rw[r].init(newval);
+#pragma unroll
+  for (int r = 0; r < G; r++) { nh[r] = 0; open_start[r] = -1; prev_cd[r] = 0; }
+  // every array is addressed as (uniform base) + (32-bit byte offset): rows differ by the uniform element offset y * W
+  // (head lists have one row of W slots per image row, so the same offset serves labels, counts and lists)
+  unsigned* const hd = heads + plane_off;
+  const unsigned y0W = (unsigned)(y0 * W);
+
+  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_BG) {
+    int vs[G + 1][SPK_BG];
+    // branch-free loads: columns clamped into the row, rows into the image; out-of-range values become newval afterwards
+#pragma unroll
+    for (int r = 0; r <= G; r++) {
+      const unsigned rowoff = (unsigned)(min(y0 + r, H - 1) * W);
+#pragma unroll
+      for (int g = 0; g < SPK_BG; g++) vs[r][g] = (int)*at32(d, rowoff + (unsigned)min(cb0 + 64 * g + lane, W - 1));
+    }
+#pragma unroll
+    for (int r = 0; r <= G; r++) {
+      const bool row_ok = y0 + r < H;   // uniform
+#pragma unroll
+      for (int g = 0; g < SPK_BG; g++) vs[r][g] = (row_ok && cb0 + 64 * g + lane < W) ? vs[r][g] : newval;
+    }
+#pragma unroll
+    for (int g = 0; g < SPK_BG; g++) {
+      const int cb = cb0 + 64 * g;
+      if (cb >= W) break;
+#pragma unroll
+      for (int r = 0; r <= G; r++) {
+        const unsigned yW = y0W + (unsigned)(r * W);
+        rw[r].step(vs[r][g], cb, lane, newval, maxdiff);
+        if (r < G) {
+          // ---- run heads of an owned row (rows beyond the image hold no valid pixel: nothing happens) ----
+          const unsigned long long hm = rw[r].head, bm = hm | ~rw[r].valid;
+          if (open_start[r] >= 0 && bm) {
+            if (lane == 0) {
+              const int len = cb + (__ffsll((long long)bm) - 1) - open_start[r];
+              *at32(C, yW + (unsigned)open_start[r]) = len;
+              *at32(hd, yW + (unsigned)(nh[r] - 1)) = (unsigned)open_start[r] | ((unsigned)len << 16);
+            }
+            open_start[r] = -1;
+          }
+          if (hm) {
+            if (lane_in(hm)) {
+              const unsigned long long above = (bm >> 1) >> lane;   // boundaries right of this lane
+              const unsigned self = yW + (unsigned)(cb + lane);
+              __hip_atomic_store(at32(L, self), (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const int len = above ? __ffsll((long long)above) : 0;   // 0: still open, closed (and overwritten) later
+              *at32(C, self) = len;
+              *at32(hd, yW + (unsigned)(nh[r] + lanes_below(hm))) = (unsigned)(cb + lane) | ((unsigned)len << 16);
+            }
+            const int hb = 63 - __clzll((long long)hm);
+            nh[r] += __popcll(hm);
+            if (hb == 63 || (bm >> (hb + 1)) == 0ull) open_start[r] = cb + hb;
+          }
+        }
+        if (r > 0) {
+          // ---- contacts between rows r-1 (upper) and r (lower) ----
+          const RowWalk& up = rw[r - 1];
+          const RowWalk& dn = rw[r];
+          const unsigned long long cdm = up.valid & dn.valid & __ballot(abs(vs[r - 1][g] - vs[r][g]) <= maxdiff);
+          const unsigned long long pcdm = (cdm << 1) | prev_cd[r - 1];
+          const unsigned long long fm = cdm & ~(pcdm & ~up.head & ~dn.head);
+          if (fm) {
+            if (lane_in(fm)) {
+              const int k = lanes_below(fm);
+              if (r < G) list[count + k] = make_int2((int)(yW - (unsigned)W) + up.start(lane), (int)yW + dn.start(lane));
+              else *at32(sl, (unsigned)(nsm + k)) = (unsigned)up.start(lane) | ((unsigned)dn.start(lane) << 16);
+            }
+            if (r < G) count += __popcll(fm);
+            else nsm += __popcll(fm);
+          }
+          prev_cd[r - 1] = (unsigned)(cdm >> 63);
+          rw[r - 1].next(vs[r - 1][g]);
+        }
+      }
+      rw[G].next(vs[G][g]);
+      if (count > SPK_BCAP - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      const int y = y0 + r;
+      if (y < H) {
+        const unsigned yW = y0W + (unsigned)(r * W);
+        if (open_start[r] >= 0) {
+          *at32(C, yW + (unsigned)open_start[r]) = W - open_start[r];
+          *at32(hd, yW + (unsigned)(nh[r] - 1)) = (unsigned)open_start[r] | ((unsigned)(W - open_start[r]) << 16);
+        }
+        nheads[(size_t)blockIdx.y * H + y] = nh[r];
+      }
+    }
+    nseam[(size_t)blockIdx.y * nbands + band] = nsm;
+  }
+  if (count) flush();
+}
+
+// seam contacts of the band walk: one wavefront per band, 64 unions at a time
+__global__ void __launch_bounds__(256) speckle_seam_kernel(int* __restrict__ labels, const unsigned* __restrict__ seam,
+                                                            const int* __restrict__ nseam, int HS, int W, int H, int G) {
+  const int lane = threadIdx.x & 63;
+  const int nbands = (H + G - 1) / G;
+  const int band = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (band >= nbands) return;
+  const int y = band * G + G - 1;   // upper row of the seam
+  if (y + 1 >= H) return;
+  int* L = labels + (size_t)blockIdx.y * W * H;
+  const unsigned* sl = seam + ((size_t)blockIdx.y * nbands + band) * HS;
+  const int n = nseam[(size_t)blockIdx.y * nbands + band];
+  for (int i = lane; i < n; i += 64) {
+    const unsigned e = sl[i];
+    uf_union(L, y * W + (int)(e & 0xffffu), (y + 1) * W + (int)(e >> 16));
+  }
+}
+
 // count and apply work on one load group (SPK_G chunks = 512 pixels) at a time: the walk COLLECTS the group's run heads in
 // a wavefront-private LDS list, then the root / size look-ups -- dependent L2 round trips -- run 64 heads at a time
 // (one latency per group instead of one per chunk that holds a head).
@@ -454,7 +628,7 @@ __global__ void __launch_bounds__(256) speckle_count_kernel(const int16_t* __res
   const int16_t* d = disp + plane_off + (size_t)y * W;
   int* L = labels + plane_off;
   int* C = counts + plane_off;
-  int* const list = head_lds[threadIdx.x >> 6];
+  int* const list = head_lds[wave];
   RowWalk rw;
   rw.init(newval);
   for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_G) {
@@ -484,7 +658,7 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
   int16_t* d = disp + plane_off + (size_t)y * W;
   const int* L = labels + plane_off;
   const int* C = counts + plane_off;
-  int* const list = head_lds[threadIdx.x >> 6];
+  int* const list = head_lds[wave];
   RowWalk rw;
   rw.init(newval);
   bool carry_kill = false;  // decision of the run that contains the pixel left of the chunk (uniform)
@@ -573,16 +747,43 @@ __global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __rest
   }
 }
 
-hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, const Geom& g,
-                          int max_size, int max_diff, hipStream_t s) {
+hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, uint32_t* seam,
+                          int32_t* nseam, const Geom& g, int max_size, int max_diff, hipStream_t s) {
   dim3 grid((g.H + 3) / 4, g.n);
   const int HS = g.W;   // adjacent valid pixels further apart than maxDiff are separate runs: up to W runs per row
   // compact head lists (column and run length packed in 16 bits each); SBM_SPECKLE_LISTS=0 forces the row-walking kernels
-  const char* e = getenv("SBM_SPECKLE_LISTS");
-  const bool lists = heads && nheads && g.W <= 65535 && !(e && atoi(e) == 0);
-  hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, lists ? heads : nullptr,
-                     lists ? nheads : nullptr, HS, g.W, g.H, g.filtered, max_diff);
-  hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
+  const int lists_env = [] { const char* e = getenv("SBM_SPECKLE_LISTS"); return e ? atoi(e) : 1; }();   // read per call: tests flip it
+  const bool lists = heads && nheads && g.W <= 65535 && lists_env != 0;
+  // band walk (runs + merge in one pass): G rows per wavefront, as many as still leave every SIMD a few wavefronts;
+  // SBM_SPECKLE_BAND=0 disables, 2/4/8 forces a band height
+  const int band_env = [] { const char* e = getenv("SBM_SPECKLE_BAND"); return e ? atoi(e) : -1; }();
+  int G = 0;
+  if (lists && seam && nseam && band_env != 0 && (long)g.W * g.H < (1L << 30)) {   // 32-bit byte offsets within an image
+    // measured (KITTI x64, 640x480 x64, UHD x4, KITTI x1): 4 rows per wavefront once that still leaves >= 4 wavefronts per
+    // SIMD, 2 rows down to ~2 per SIMD, below that the one-row kernels (the walk of a band is a serial chain; 8 rows per
+    // wavefront was never the fastest)
+    const long rows = (long)g.n * g.H;
+    G = rows >= 16384 ? 4 : rows >= 2048 ? 2 : 0;
+    if (band_env == 2 || band_env == 4 || band_env == 8) G = band_env;
+  }
+  if (G) {
+    const int nbands = (g.H + G - 1) / G;
+    dim3 bgrid((nbands + 3) / 4, g.n);
+    if (G == 8)
+      hipLaunchKernelGGL(speckle_band_kernel<8>, bgrid, dim3(256), 0, s, disp, labels, counts, heads, nheads, seam, nseam, HS,
+                         g.W, g.H, g.filtered, max_diff);
+    else if (G == 4)
+      hipLaunchKernelGGL(speckle_band_kernel<4>, bgrid, dim3(256), 0, s, disp, labels, counts, heads, nheads, seam, nseam, HS,
+                         g.W, g.H, g.filtered, max_diff);
+    else
+      hipLaunchKernelGGL(speckle_band_kernel<2>, bgrid, dim3(256), 0, s, disp, labels, counts, heads, nheads, seam, nseam, HS,
+                         g.W, g.H, g.filtered, max_diff);
+    hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, labels, seam, nseam, HS, g.W, g.H, G);
+  } else {
+    hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, lists ? heads : nullptr,
+                       lists ? nheads : nullptr, HS, g.W, g.H, g.filtered, max_diff);
+    hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
+  }
   if (lists) {
     hipLaunchKernelGGL(speckle_count_list_kernel, grid, dim3(256), 0, s, labels, counts, heads, nheads, HS, g.W, g.H, max_size);
     hipLaunchKernelGGL(speckle_apply_list_kernel, grid, dim3(256), 0, s, disp, labels, counts, heads, nheads, HS, g.W, g.H,
