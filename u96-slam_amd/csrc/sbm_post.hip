@@ -218,25 +218,30 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 // ---------------------------------------------------------------------------------------------------------
 // find with path halving: a visited node is re-pointed at its grandparent with a fire-and-forget atomicMin (parents only
 // ever move towards the root, so concurrent hooks are never undone)
+// SCOPE: agent where wavefronts of other workgroups (possibly on another XCD, behind another L2) union into the same
+// labels; workgroup where only the calling wavefront touches them during the kernel (band walk): those atomics are served by
+// the XCD's own L2 instead of going out to the fabric -- several times shorter dependent round trips.
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
 __device__ __forceinline__ int uf_find(int* L, int i) {
   int r = i;
   for (;;) {
-    const int p = __hip_atomic_load(L + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int p = __hip_atomic_load(L + r, __ATOMIC_RELAXED, SCOPE);
     if (p == r) return r;
-    const int gp = __hip_atomic_load(L + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int gp = __hip_atomic_load(L + p, __ATOMIC_RELAXED, SCOPE);
     if (gp == p) return p;
-    __hip_atomic_fetch_min(L + r, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_min(L + r, gp, __ATOMIC_RELAXED, SCOPE);
     r = gp;
   }
 }
 
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
 __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   for (;;) {
-    a = uf_find(L, a);
-    b = uf_find(L, b);
+    a = uf_find<SCOPE>(L, a);
+    b = uf_find<SCOPE>(L, b);
     if (a == b) return;
     if (a > b) { const int t = a; a = b; b = t; }
-    const int old = atomicMin(L + b, a);
+    const int old = __hip_atomic_fetch_min(L + b, a, __ATOMIC_RELAXED, SCOPE);
     if (old == b) return;
     b = old;
   }
@@ -253,7 +258,7 @@ __device__ __forceinline__ int uf_root_final(const int* L, int i) {
 // pixels, run heads) that cost a handful of compares plus scalar mask algebra; the per-lane "column where my run
 // starts" -- the expensive part -- is only computed on demand (start()), i.e. in the few chunks where a kernel has
 // something to do (a vertical contact, a run to erase). State carried across chunks: prev_last (value left of the
-// chunk), lvalid (that pixel is valid), carry (run start of the pixel left of the chunk, -1 if it is invalid).
+// chunk; invalid pixels hold newval), carry (column of the row's last run head so far).
 // lane predicate / prefix count of a wavefront-uniform mask without per-lane 64-bit arithmetic (exec := mask; v_mbcnt)
 __device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ int lanes_below(unsigned long long m) {
@@ -267,36 +272,33 @@ __device__ __forceinline__ T* at32(T* base, unsigned idx) {
 }
 
 struct RowWalk {
-  int prev_last, carry, cb;
-  unsigned lvalid;                  // 1 when the pixel left of the chunk is valid (kept as a shifted mask bit: a bool would
-                                    // be widened through a VALU select)
+  int prev_last, carry, cb;         // value left of the chunk; column of the last run head seen so far in the row
   unsigned long long valid, head;   // uniform
-  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; lvalid = 0; }
-  // masks of the chunk at column cb_ (lanes beyond the row hold newval = invalid)
+  __device__ __forceinline__ void init(int newval) { prev_last = newval; carry = -1; }
+  // masks of the chunk at column cb_ (lanes beyond the row hold newval = invalid); maxdiff <= 2^17 (launcher clamps it)
   __device__ __forceinline__ void step(int v, int cb_, int lane, int newval, int maxdiff) {
     cb = cb_;
     // value of the left neighbour: full-rate DPP wave shift; lane 0 has no source lane and keeps `old` = prev_last
     // (__shfl_up would be a ds_bpermute_b32 -- an LDS crossbar round trip inside the serial chain of the walk)
     const int pv = __builtin_amdgcn_update_dpp(prev_last, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     valid = __ballot(v != newval);
-    const unsigned long long closem = __ballot(abs(v - pv) <= maxdiff);
-    const unsigned long long pvalid = (valid << 1) | lvalid;
-    head = valid & ~(pvalid & closem);
+    // distance to the left neighbour, "far" when that pixel is invalid (invalid pixels hold newval): one compare then
+    // yields the lanes that are NOT joined to the left, instead of mask algebra on the scalar unit (these walks are bound
+    // by scalar issue: one SALU instruction per SIMD every 4 cycles)
+    const int dist = pv != newval ? abs(v - pv) : 0x40000000;
+    head = valid & __ballot(dist > maxdiff);
   }
-  // column where the lane's run starts (meaningful for valid lanes)
+  // column where the lane's run starts (meaningful for valid lanes: a valid lane with no head at or below it in this chunk
+  // is joined, through valid pixels only, to the last head of the earlier chunks)
   __device__ __forceinline__ int start(int lane) const {
     const unsigned long long t = head << (63 - lane);   // heads at or below this lane, the nearest one in bit 63
     return t ? cb + lane - __clzll((long long)t) : carry;
   }
   // advance the carried state to the next chunk (uniform arithmetic only)
   __device__ __forceinline__ void next(int v) {
-    const bool v63 = (valid >> 63) & 1ull;
-    carry = v63 ? (head ? cb + (63 - __clzll((long long)head)) : carry) : -1;
-    lvalid = (unsigned)(valid >> 63);
+    carry = head ? cb + (63 - __clzll((long long)head)) : carry;
     prev_last = __builtin_amdgcn_readlane(v, 63);
   }
-  // bit position (0..63) of the head of the run that contains pixel 63 of this chunk, -1 if that run started earlier
-  __device__ __forceinline__ int last_head_bit() const { return head ? 63 - __clzll((long long)head) : -1; }
 };
 
 // Rows are walked in groups of SPK_G chunks whose values are loaded up front (SPK_G independent loads in flight per
@@ -318,19 +320,14 @@ __device__ __forceinline__ void spk_load_group(const int16_t* d, int cb0, int W,
   (void)lane;
 
 // grid: (ceil(H/4), n), block 256 = 4 wavefronts = 4 rows
-// With `heads` != nullptr the row's run heads are also appended, in column order, to a compact list
-// (heads[row][k] = column | run length << 16, nheads[row]) so that the count and apply kernels need not walk the rows again.
 __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
-                                                            int* __restrict__ counts, unsigned* __restrict__ heads,
-                                                            int* __restrict__ nheads, int HS, int W, int H, int newval,
+                                                            int* __restrict__ counts, int W, int H, int newval,
                                                             int maxdiff) {
   SPK_ROW_SETUP
   if (y >= H) return;
   const int16_t* d = disp + plane_off + (size_t)y * W;
   int* L = labels + plane_off + (size_t)y * W;
   int* C = counts + plane_off + (size_t)y * W;
-  unsigned* hl = heads ? heads + ((size_t)blockIdx.y * H + y) * HS : nullptr;
-  int nh = 0, open_k = -1;   // uniform: heads listed so far, list slot of the run that is still open
   // every head learns the distance to the next boundary (head, invalid pixel or row end). A run that leaves its chunk
   // stays "open" (uniform state) and is closed by the first boundary of a later chunk.
   RowWalk rw;
@@ -346,35 +343,22 @@ __global__ void __launch_bounds__(256) speckle_runs_kernel(const int16_t* __rest
       rw.step(vs[g], cb, lane, newval, maxdiff);
       const unsigned long long hm = rw.head, bm = hm | ~rw.valid;   // lanes beyond W are invalid = boundary
       if (open_start >= 0 && bm) {
-        if (lane == 0) {
-          const int len = cb + (__ffsll((long long)bm) - 1) - open_start;
-          C[open_start] = len;
-          if (hl) hl[open_k] = (unsigned)open_start | ((unsigned)len << 16);
-        }
+        if (lane == 0) C[open_start] = cb + (__ffsll((long long)bm) - 1) - open_start;
         open_start = -1;
       }
       if (hm) {                                                      // uniform: most chunks hold no run head
         if ((hm >> lane) & 1ull) {
           const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
           L[cb + lane] = y * W + cb + lane;
-          const int len = above ? __ffsll((long long)above) : 0;    // 0: closed by a later chunk (or the row end)
-          if (above) C[cb + lane] = len;
-          if (hl) hl[nh + __popcll(hm & ((1ull << lane) - 1ull))] = (unsigned)(cb + lane) | ((unsigned)len << 16);
+          if (above) C[cb + lane] = __ffsll((long long)above);      // else: closed by a later chunk (or the row end)
         }
         const int hb = 63 - __clzll((long long)hm);                  // the last head stays open if nothing bounds it
-        nh += __popcll(hm);
-        if (hb == 63 || (bm >> (hb + 1)) == 0ull) { open_start = cb + hb; open_k = nh - 1; }
+        if (hb == 63 || (bm >> (hb + 1)) == 0ull) open_start = cb + hb;
       }
       rw.next(vs[g]);
     }
   }
-  if (lane == 0) {
-    if (open_start >= 0) {
-      C[open_start] = W - open_start;
-      if (hl) hl[open_k] = (unsigned)open_start | ((unsigned)(W - open_start) << 16);
-    }
-    if (nheads) nheads[(size_t)blockIdx.y * H + y] = nh;
-  }
+  if (lane == 0 && open_start >= 0) C[open_start] = W - open_start;
 }
 
 // The row walk only COLLECTS the contacts (pairs of run heads) into a wavefront-private LDS list; the unions -- chains
@@ -469,91 +453,115 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < count; i += 64) {
       const int2 c = list[i];
-      uf_union(L, c.x, c.y);
+      uf_union<__HIP_MEMORY_SCOPE_WORKGROUP>(L, c.x, c.y);
     }
     __builtin_amdgcn_wave_barrier();
     count = 0;
   };
   RowWalk rw[G + 1];
-  int nh[G], open_start[G];   // heads listed so far; start of the run still open (its list slot is nh - 1)
+  int nh[G], ne[G];           // run starts / run ends listed so far
+  unsigned pend[G];           // 1: the pixel left of the chunk is valid and its run end is not settled yet
   unsigned prev_cd[G];        // vertical contact between rows r and r+1 at the pixel left of the chunk (0 / 1)
 #pragma unroll
   for (int r = 0; r <= G; r++) rw[r].init(newval);
 #pragma unroll
-  for (int r = 0; r < G; r++) { nh[r] = 0; open_start[r] = -1; prev_cd[r] = 0; }
+  for (int r = 0; r < G; r++) { nh[r] = 0; ne[r] = 0; pend[r] = 0; prev_cd[r] = 0; }
   // every array is addressed as (uniform base) + (32-bit byte offset): rows differ by the uniform element offset y * W
   // (head lists have one row of W slots per image row, so the same offset serves labels, counts and lists)
-  unsigned* const hd = heads + plane_off;
-  const unsigned y0W = (unsigned)(y0 * W);
+  // the row's W list slots (4 bytes each) hold two 16-bit lists: run starts in the first half, run ends in the second
+  unsigned short* const st = reinterpret_cast<unsigned short*>(heads + plane_off);
+  unsigned short* const en = st + W;
+  const unsigned y0W = (unsigned)(y0 * W);        // pixel index of the band's first row; its lists start at element 2 * y0W
 
-  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_BG) {
-    int vs[G + 1][SPK_BG];
-    // branch-free loads: columns clamped into the row, rows into the image; out-of-range values become newval afterwards
+  // Loads and stores share one counter (vmcnt) and may complete out of order, so a wait for a load with stores in flight
+  // is a wait for ALL of them -- a store acknowledgement (~1 us) per chunk when loads are consumed chunk by chunk. Hence:
+  // a group's values are consumed (pinned) before the group's first store, and the next group's loads are issued right
+  // then, so that they are in flight during this group's arithmetic and stores.
+  int vn[G + 1][SPK_BG];
+  auto load_group = [&](int cb0) {
+    // branch-free: columns clamped into the row, rows into the image; out-of-range values become newval when consumed
 #pragma unroll
     for (int r = 0; r <= G; r++) {
       const unsigned rowoff = (unsigned)(min(y0 + r, H - 1) * W);
 #pragma unroll
-      for (int g = 0; g < SPK_BG; g++) vs[r][g] = (int)*at32(d, rowoff + (unsigned)min(cb0 + 64 * g + lane, W - 1));
+      for (int g = 0; g < SPK_BG; g++) vn[r][g] = (int)*at32(d, rowoff + (unsigned)min(cb0 + 64 * g + lane, W - 1));
     }
+  };
+  load_group(0);
+  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_BG) {
+    int vs[G + 1][SPK_BG];
 #pragma unroll
     for (int r = 0; r <= G; r++) {
       const bool row_ok = y0 + r < H;   // uniform
 #pragma unroll
-      for (int g = 0; g < SPK_BG; g++) vs[r][g] = (row_ok && cb0 + 64 * g + lane < W) ? vs[r][g] : newval;
+      for (int g = 0; g < SPK_BG; g++) {
+        vs[r][g] = (row_ok && cb0 + 64 * g + lane < W) ? vn[r][g] : newval;
+        asm volatile("" : "+v"(vs[r][g]));   // consumed here, not at the first use further down
+      }
     }
+    if (cb0 + 64 * SPK_BG < W) load_group(cb0 + 64 * SPK_BG);
 #pragma unroll
     for (int g = 0; g < SPK_BG; g++) {
       const int cb = cb0 + 64 * g;
       if (cb >= W) break;
+      // phase 1 (straight-line, rows independent: the scheduler interleaves their dependency chains): masks of every row,
+      // first pixels of the vertical contacts of every row pair
 #pragma unroll
-      for (int r = 0; r <= G; r++) {
+      for (int r = 0; r <= G; r++) rw[r].step(vs[r][g], cb, lane, newval, maxdiff);
+      unsigned long long fms[G];
+#pragma unroll
+      for (int r = 1; r <= G; r++) {
+        const RowWalk& up = rw[r - 1];
+        const RowWalk& dn = rw[r];
+        // the lower pixel counts as far away when it is invalid, so one compare and the upper row's mask give the contacts
+        const int vd = vs[r][g] != newval ? vs[r][g] : 0x40000000;
+        const unsigned long long cdm = up.valid & __ballot(abs(vs[r - 1][g] - vd) <= maxdiff);
+        const unsigned long long pcdm = (cdm << 1) | prev_cd[r - 1];
+        fms[r - 1] = cdm & (up.head | dn.head | ~pcdm);
+        prev_cd[r - 1] = (unsigned)(cdm >> 63);
+      }
+      // phase 2: run heads and run ends of the owned rows, appended in column order to the row's two compact lists (the
+      // k-th start and the k-th end belong to the same run). An end is a valid pixel whose right neighbour is a boundary
+      // (a head or an invalid pixel); for lane 63 that neighbour belongs to the next chunk, so it is settled there.
+      // Rows beyond the image hold no valid pixel: nothing happens.
+#pragma unroll
+      for (int r = 0; r < G; r++) {
         const unsigned yW = y0W + (unsigned)(r * W);
-        rw[r].step(vs[r][g], cb, lane, newval, maxdiff);
-        if (r < G) {
-          // ---- run heads of an owned row (rows beyond the image hold no valid pixel: nothing happens) ----
-          const unsigned long long hm = rw[r].head, bm = hm | ~rw[r].valid;
-          if (open_start[r] >= 0 && bm) {
-            if (lane == 0) {
-              const int len = cb + (__ffsll((long long)bm) - 1) - open_start[r];
-              *at32(C, yW + (unsigned)open_start[r]) = len;
-              *at32(hd, yW + (unsigned)(nh[r] - 1)) = (unsigned)open_start[r] | ((unsigned)len << 16);
-            }
-            open_start[r] = -1;
-          }
-          if (hm) {
-            if (lane_in(hm)) {
-              const unsigned long long above = (bm >> 1) >> lane;   // boundaries right of this lane
-              const unsigned self = yW + (unsigned)(cb + lane);
-              __hip_atomic_store(at32(L, self), (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              const int len = above ? __ffsll((long long)above) : 0;   // 0: still open, closed (and overwritten) later
-              *at32(C, self) = len;
-              *at32(hd, yW + (unsigned)(nh[r] + lanes_below(hm))) = (unsigned)(cb + lane) | ((unsigned)len << 16);
-            }
-            const int hb = 63 - __clzll((long long)hm);
-            nh[r] += __popcll(hm);
-            if (hb == 63 || (bm >> (hb + 1)) == 0ull) open_start[r] = cb + hb;
-          }
+        const unsigned long long hm = rw[r].head, bm = hm | ~rw[r].valid;
+        if (pend[r] & (unsigned)bm) {            // (bit 0 of both) the previous chunk's last pixel ended its run
+          if (lane == 0) *at32(en, 2u * yW + (unsigned)ne[r]) = (unsigned short)(cb - 1);
+          ne[r]++;
         }
-        if (r > 0) {
-          // ---- contacts between rows r-1 (upper) and r (lower) ----
-          const RowWalk& up = rw[r - 1];
-          const RowWalk& dn = rw[r];
-          const unsigned long long cdm = up.valid & dn.valid & __ballot(abs(vs[r - 1][g] - vs[r][g]) <= maxdiff);
-          const unsigned long long pcdm = (cdm << 1) | prev_cd[r - 1];
-          const unsigned long long fm = cdm & ~(pcdm & ~up.head & ~dn.head);
-          if (fm) {
-            if (lane_in(fm)) {
-              const int k = lanes_below(fm);
-              if (r < G) list[count + k] = make_int2((int)(yW - (unsigned)W) + up.start(lane), (int)yW + dn.start(lane));
-              else *at32(sl, (unsigned)(nsm + k)) = (unsigned)up.start(lane) | ((unsigned)dn.start(lane) << 16);
-            }
-            if (r < G) count += __popcll(fm);
-            else nsm += __popcll(fm);
+        const unsigned long long em = rw[r].valid & (bm >> 1);
+        if (lane_in(hm)) {
+          const unsigned self = yW + (unsigned)(cb + lane);
+          __hip_atomic_store(at32(L, self), (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          *at32(C, self) = 0;                   // component sizes are accumulated by the count kernel
+          *at32(st, 2u * yW + (unsigned)(nh[r] + lanes_below(hm))) = (unsigned short)(cb + lane);
+        }
+        if (lane_in(em)) *at32(en, 2u * yW + (unsigned)(ne[r] + lanes_below(em))) = (unsigned short)(cb + lane);
+        nh[r] += __popcll(hm);
+        ne[r] += __popcll(em);
+        pend[r] = (unsigned)(rw[r].valid >> 63);
+      }
+      // phase 3: list the contacts (in-band: LDS, unioned at the next flush; seam: the band's global list)
+#pragma unroll
+      for (int r = 1; r <= G; r++) {
+        const unsigned long long fm = fms[r - 1];
+        if (fm) {
+          const unsigned yW = y0W + (unsigned)(r * W);
+          if (lane_in(fm)) {
+            const int k = lanes_below(fm);
+            const int su = rw[r - 1].start(lane), sd = rw[r].start(lane);
+            if (r < G) list[count + k] = make_int2((int)(yW - (unsigned)W) + su, (int)yW + sd);
+            else *at32(sl, (unsigned)(nsm + k)) = (unsigned)su | ((unsigned)sd << 16);
           }
-          prev_cd[r - 1] = (unsigned)(cdm >> 63);
-          rw[r - 1].next(vs[r - 1][g]);
+          if (r < G) count += __popcll(fm);
+          else nsm += __popcll(fm);
         }
       }
+#pragma unroll
+      for (int r = 0; r < G; r++) rw[r].next(vs[r][g]);
       rw[G].next(vs[G][g]);
       if (count > SPK_BCAP - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
     }
@@ -564,10 +572,7 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
       const int y = y0 + r;
       if (y < H) {
         const unsigned yW = y0W + (unsigned)(r * W);
-        if (open_start[r] >= 0) {
-          *at32(C, yW + (unsigned)open_start[r]) = W - open_start[r];
-          *at32(hd, yW + (unsigned)(nh[r] - 1)) = (unsigned)open_start[r] | ((unsigned)(W - open_start[r]) << 16);
-        }
+        if (pend[r]) *at32(en, 2u * yW + (unsigned)ne[r]) = (unsigned short)(W - 1);   // W a multiple of 64: the row's last pixel
         nheads[(size_t)blockIdx.y * H + y] = nh[r];
       }
     }
@@ -703,7 +708,8 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
   }
 }
 
-// ---- list-driven count / apply: one wavefront per row, one lane per run head of the row's compact list --------------------
+// ---- list-driven count / apply: one wavefront per row, one lane per run of the row's compact lists (band walk) -----------
+// (run k of a row: columns starts[k] .. ends[k], two 16-bit lists in the row's W four-byte slots)
 __global__ void __launch_bounds__(256) speckle_count_list_kernel(int* __restrict__ labels, int* __restrict__ counts,
                                                                   const unsigned* __restrict__ heads,
                                                                   const int* __restrict__ nheads, int HS, int W, int H,
@@ -713,16 +719,17 @@ __global__ void __launch_bounds__(256) speckle_count_list_kernel(int* __restrict
   int* L = labels + plane_off;
   int* C = counts + plane_off;
   const size_t row = (size_t)blockIdx.y * H + y;
-  const unsigned* hl = heads + row * HS;
+  const unsigned short* st = reinterpret_cast<const unsigned short*>(heads + row * HS);
+  const unsigned short* en = st + W;
   const int nh = nheads[row];
   for (int i = lane; i < nh; i += 64) {
-    const unsigned e = hl[i];
-    const int self = y * W + (int)(e & 0xffffu);
+    const int x = st[i], len = (int)en[i] - x + 1;
+    const int self = y * W + x;
     const int r = uf_root_final(L, self);
-    if (r != self) {
-      L[self] = r;   // parents are final: point straight at the root so the apply kernel's lookup is one step
-      if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, (int)(e >> 16));
-    }
+    if (r != self) L[self] = r;   // parents are final: point straight at the root so the apply kernel's lookup is one step
+    // every run adds its length to the root's (zero-initialised) count, unless the component is already known to exceed
+    // maxSpeckleSize (saturating: exact where it matters, no contention on large components)
+    if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, len);
   }
 }
 
@@ -737,33 +744,34 @@ __global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __rest
   const int* L = labels + plane_off;
   const int* C = counts + plane_off;
   const size_t row = (size_t)blockIdx.y * H + y;
-  const unsigned* hl = heads + row * HS;
+  const unsigned short* st = reinterpret_cast<const unsigned short*>(heads + row * HS);
+  const unsigned short* en = st + W;
   const int nh = nheads[row];
   for (int i = lane; i < nh; i += 64) {
-    const unsigned e = hl[i];
-    const int x = (int)(e & 0xffffu), len = (int)(e >> 16);
+    const int x = st[i], xe = en[i];
     if (C[uf_root_final(L, y * W + x)] <= maxsize)          // a speckle: its runs are at most maxsize long
-      for (int j = 0; j < len; j++) d[x + j] = (int16_t)newval;
+      for (int j = x; j <= xe; j++) d[j] = (int16_t)newval;
   }
 }
 
 hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, uint32_t* seam,
                           int32_t* nseam, const Geom& g, int max_size, int max_diff, hipStream_t s) {
   dim3 grid((g.H + 3) / 4, g.n);
-  const int HS = g.W;   // adjacent valid pixels further apart than maxDiff are separate runs: up to W runs per row
-  // compact head lists (column and run length packed in 16 bits each); SBM_SPECKLE_LISTS=0 forces the row-walking kernels
+  max_diff = std::min(max_diff, 1 << 17);   // int16 values: any larger range joins everything alike
+  const int HS = g.W;   // list slots per row: adjacent valid pixels further apart than maxDiff are separate runs, up to W per row
+  // Two implementations. Default: band walk (runs + merge in one pass, G rows per wavefront) + seam unions, then count and
+  // apply driven by the rows' compact run lists (16-bit columns: W <= 65535; 32-bit byte offsets within an image).
+  // Fallback (SBM_SPECKLE_LISTS=0 or SBM_SPECKLE_BAND=0, or outside those limits): four kernels that each walk the rows.
   const int lists_env = [] { const char* e = getenv("SBM_SPECKLE_LISTS"); return e ? atoi(e) : 1; }();   // read per call: tests flip it
-  const bool lists = heads && nheads && g.W <= 65535 && lists_env != 0;
-  // band walk (runs + merge in one pass): G rows per wavefront, as many as still leave every SIMD a few wavefronts;
-  // SBM_SPECKLE_BAND=0 disables, 2/4/8 forces a band height
   const int band_env = [] { const char* e = getenv("SBM_SPECKLE_BAND"); return e ? atoi(e) : -1; }();
+  const bool lists = heads && nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 30) && lists_env != 0 &&
+                     band_env != 0;
   int G = 0;
-  if (lists && seam && nseam && band_env != 0 && (long)g.W * g.H < (1L << 30)) {   // 32-bit byte offsets within an image
+  if (lists) {
     // measured (KITTI x64, 640x480 x64, UHD x4, KITTI x1): 4 rows per wavefront once that still leaves >= 4 wavefronts per
-    // SIMD, 2 rows down to ~2 per SIMD, below that the one-row kernels (the walk of a band is a serial chain; 8 rows per
-    // wavefront was never the fastest)
-    const long rows = (long)g.n * g.H;
-    G = rows >= 16384 ? 4 : rows >= 2048 ? 2 : 0;
+    // SIMD, else 2 (the walk of a band is a serial chain; 8 rows per wavefront was never the fastest). SBM_SPECKLE_BAND=2/4/8
+    // forces a band height.
+    G = (long)g.n * g.H >= 16384 ? 4 : 2;
     if (band_env == 2 || band_env == 4 || band_env == 8) G = band_env;
   }
   if (G) {
@@ -780,8 +788,7 @@ hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint3
                          g.W, g.H, g.filtered, max_diff);
     hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, labels, seam, nseam, HS, g.W, g.H, G);
   } else {
-    hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, lists ? heads : nullptr,
-                       lists ? nheads : nullptr, HS, g.W, g.H, g.filtered, max_diff);
+    hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff);
     hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
   }
   if (lists) {
