@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "sbm_common.h"
 
@@ -84,9 +85,14 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
   }
 }
 
-// Fast variant for the 16-bit cost plane (fast + border SAD kernels) and W <= 256*NPT: the row's disparities and
-// costs are loaded once, up front (NPT independent loads per lane), the row is kept in LDS so the winner's disparity
-// is an LDS read, and the claim key is 32 bits (cost << 16 | x) -> ds_min_u32.
+// Fast variant for the 16-bit cost plane (fast + border SAD kernels) and W <= 256*NPT: the row's disparities and costs are
+// loaded once, up front (NPT independent loads per lane), and the claim on a right-view column is ONE 32-bit LDS word,
+// (cost << 16) | (disparity ^ 0x8000), taken with ds_min_u32. The winner's disparity rides in the key: among the claimants of
+// one column x2 = x - round(d/16) a smaller x means a strictly smaller d, so "lowest cost, then lowest d" picks the pixel that
+// cv's "lowest cost, then lowest x" picks -- no second look-up of the winner's disparity, no copy of the row in LDS.
+// Layout: key[0] front pad (column -1), key[1 + x] column x, key[W+1], key[W+2] "no claimant" (targets outside the row read
+// here), then 64 per-lane dummy slots that absorb the claims of pixels that make none (branch-free ds_min).
+// This kernel is bound by VALU issue (about 40 instructions per pixel slot), not by memory.
 extern __shared__ __attribute__((aligned(16))) unsigned lr_lds32[];
 
 template <int NIT>
@@ -99,83 +105,97 @@ __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
     for (int x = threadIdx.x; x < a.W; x += BS) out[x] = (int16_t)a.filtered;
     return;
   }
-  unsigned* keys = lr_lds32;                                                        // [W4]
-  const int W4 = (a.W + 3) & ~3;
-  int16_t* srow = reinterpret_cast<int16_t*>(lr_lds32 + W4);                        // [W4] pre-LR disparities of the row
+  unsigned* const key = lr_lds32;
+  const int W = a.W;
   const int16_t* dp = a.disp_pre + base;
   const uint16_t* cp = static_cast<const uint16_t*>(a.cost) + base;
   const int INV = a.filtered;
-  const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(a.W + min(a.mindisp, 0), a.cx1);
+  const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(W + min(a.mindisp, 0), a.cx1);
+  constexpr unsigned NONE = 0xffffffffu;   // real keys stay below 0xffff0000 (costs <= 65534 in this envelope)
+  // A wavefront's 256 columns of one iteration usually lie inside every column range that matters (computed columns,
+  // checked columns, valid ROI, the row itself): those iterations skip all per-pixel range tests (uniform branch).
+  const int wbase = 4 * __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  const int lo = max(max(minX1, a.cx0), a.col0), hi = min(min(maxX1, a.cx1), min(a.col1, W));
+  bool inner[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; k++) inner[k] = wbase + 4 * BS * k >= lo && wbase + 4 * BS * k + 256 <= hi;
   // a thread owns 4 adjacent pixels per iteration: 8-byte loads / stores (rows are only 2-byte aligned: unaligned ones)
   int dv[NIT][4];
-  unsigned cv[NIT][4];
-#pragma unroll
-  for (int k = 0; k < NIT; k++) {
+  unsigned kv[NIT][4];
+  auto load = [&](auto inner_t, const int k) {
+    constexpr bool IN = decltype(inner_t)::value;
     const int x0 = 4 * (threadIdx.x + BS * k);
     short dd[4] = {0, 0, 0, 0};
     unsigned short cc[4] = {0, 0, 0, 0};
-    if (x0 + 4 <= a.W) {
+    if (IN || x0 + 4 <= W) {
       __builtin_memcpy(dd, dp + x0, 8);
       __builtin_memcpy(cc, cp + x0, 8);
     } else {
-      for (int i = 0; x0 + i < a.W; i++) { dd[i] = dp[x0 + i]; cc[i] = cp[x0 + i]; }
+      for (int i = 0; x0 + i < W; i++) { dd[i] = dp[x0 + i]; cc[i] = cp[x0 + i]; }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int x = x0 + i;
-      dv[k][i] = (x >= a.cx0 && x < a.cx1) ? (int)dd[i] : INV;
-      cv[k][i] = (x >= minX1 && x < maxX1) ? (unsigned)cc[i] : 0u;
+      dv[k][i] = (IN || (x >= a.cx0 && x < a.cx1)) ? (int)dd[i] : INV;
+      kv[k][i] = ((unsigned)cc[i] << 16) | ((unsigned)(unsigned short)dd[i] ^ 0x8000u);
     }
-  }
-#pragma unroll
-  for (int k = 0; k < NIT; k++) {
-    const int x0 = 4 * (threadIdx.x + BS * k);
-    if (x0 < W4) {
-      *reinterpret_cast<uint4*>(keys + x0) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-      const unsigned lo = (unsigned)(dv[k][0] & 0xffff) | ((unsigned)dv[k][1] << 16);
-      const unsigned hi = (unsigned)(dv[k][2] & 0xffff) | ((unsigned)dv[k][3] << 16);
-      *reinterpret_cast<uint2*>(srow + x0) = make_uint2(lo, hi);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NIT; k++) {
+  };
+  const int dummy = W + 3 + (threadIdx.x & 63);
+  auto claim = [&](auto inner_t, const int k) {
+    constexpr bool IN = decltype(inner_t)::value;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int x = 4 * (threadIdx.x + BS * k) + i;
       const int d = dv[k][i];
-      if (x >= minX1 && x < maxX1 && d != INV) {
-        const int x2 = x - ((d + 8) >> 4);
-        if (x2 >= 0 && x2 < a.W) atomicMin(&keys[x2], (cv[k][i] << 16) | (unsigned)x);
-      }
+      const int x2 = x - ((d + 8) >> 4);
+      const bool claims = d != INV && (IN || (x >= minX1 && x < maxX1)) && (unsigned)x2 < (unsigned)W;
+      __hip_atomic_fetch_min(&key[claims ? x2 + 1 : dummy], kv[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NIT; k++) {
+  };
+  auto check = [&](auto inner_t, const int k) {
+    constexpr bool IN = decltype(inner_t)::value;
     const int x0 = 4 * (threadIdx.x + BS * k);
-    if (x0 >= a.W) continue;
+    if (x0 >= W) return;
     short res[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int x = x0 + i;
-      // branch-free: the look-ups read slot 0 when they do not apply (four nested conditionals per pixel cost more in
-      // exec-mask bookkeeping than the two spare LDS reads)
       const int d = dv[k][i];
-      const bool live = d != INV && x >= minX1 && x < maxX1;
-      const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
-      const bool ia = live && (unsigned)xa < (unsigned)a.W, ib = live && (unsigned)xb < (unsigned)a.W;
-      const unsigned ka = keys[ia ? xa : 0], kb = keys[ib ? xb : 0];
-      const bool ha = ia && ka != 0xffffffffu, hb = ib && kb != 0xffffffffu;
-      const int da = srow[ha ? (ka & 0xffffu) : 0u], db = srow[hb ? (kb & 0xffffu) : 0u];
-      const bool bad = ha && hb && abs(da - d) > a.tol && abs(db - d) > a.tol;
-      res[i] = (short)((x < a.col0 || x >= a.col1 || bad) ? INV : d);
+      // targets x - floor(d/16) and x - ceil(d/16): the same column or two adjacent ones -> one two-word read. A pixel that
+      // is not checked, or whose floor target lies outside the row, reads "no claimant" twice (it cannot fail then: both
+      // targets must disagree); a ceil target of -1 reads the front pad.
+      const int xa = x - (d >> 4);
+      const bool checked = d != INV && (IN || (x >= minX1 && x < maxX1)) && (unsigned)xa < (unsigned)W;
+      const int p = checked ? xa : W + 1;
+      const unsigned k0 = key[p], k1 = key[p + 1];          // claims of columns xa-1, xa
+      const unsigned ka = k1, kb = (d & 15) ? k0 : k1;
+      const int da = (int)(ka & 0xffffu) - 0x8000, db = (int)(kb & 0xffffu) - 0x8000;
+      const bool bad = ka < 0xffff0000u && kb < 0xffff0000u && abs(da - d) > a.tol && abs(db - d) > a.tol;
+      res[i] = (short)(((!IN && (x < a.col0 || x >= a.col1)) || bad) ? INV : d);
     }
-    if (x0 + 4 <= a.W) {
+    if (IN || x0 + 4 <= W) {
       __builtin_memcpy(out + x0, res, 8);
     } else {
-      for (int i = 0; x0 + i < a.W; i++) out[x0 + i] = res[i];
+      for (int i = 0; x0 + i < W; i++) out[x0 + i] = res[i];
     }
+  };
+#pragma unroll
+  for (int k = 0; k < NIT; k++) {
+    if (inner[k]) load(std::true_type{}, k);
+    else load(std::false_type{}, k);
+  }
+  for (int i = 4 * threadIdx.x; i < W + 3; i += 4 * BS) *reinterpret_cast<uint4*>(key + i) = make_uint4(NONE, NONE, NONE, NONE);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NIT; k++) {
+    if (inner[k]) claim(std::true_type{}, k);
+    else claim(std::false_type{}, k);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NIT; k++) {
+    if (inner[k]) check(std::true_type{}, k);
+    else check(std::false_type{}, k);
   }
 }
 
@@ -187,14 +207,17 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
   a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
   a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;
   if (a.do_lr && g.cost16 && g.W <= 4096) {
-    const size_t lds16 = (size_t)((g.W + 3) & ~3) * 6 + 16;
-    // 4 pixels per thread and iteration; narrow rows get a narrower block (640 columns: 192 threads, LR 0.049 -> 0.039 ms),
-    // wider rows keep 256 threads and iterate (row-wide blocks of up to 1024 threads measured slower at 1242 and 3840)
+    const size_t lds16 = (size_t)(g.W + 3 + 64 + 8) * sizeof(unsigned);   // claims, pads, per-lane dummy slots
+    // 4 pixels per thread and iteration; the fewest iterations that fit a block of <= 256 threads, and then the narrowest
+    // block (a multiple of 64) that covers the row: idle wavefronts still occupy wavefront slots, and this kernel's speed is
+    // set by how many rows a CU holds at once (640 columns: 192 threads, 1242: 2 x 192; blocks wider than 256 threads
+    // measured slower at 1242, 1920 and 3840).
     const int groups = (g.W + 3) / 4;
-    const int bs = std::min(256, ((groups + 63) / 64) * 64);
-    if (groups <= 256) hipLaunchKernelGGL(lrcheck16_kernel<1>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
-    else if (groups <= 512) hipLaunchKernelGGL(lrcheck16_kernel<2>, dim3(g.H, g.n), dim3(256), lds16, s, a);
-    else hipLaunchKernelGGL(lrcheck16_kernel<4>, dim3(g.H, g.n), dim3(256), lds16, s, a);
+    const int nit = groups <= 256 ? 1 : groups <= 512 ? 2 : 4;
+    const int bs = (((groups + nit - 1) / nit + 63) / 64) * 64;   // (one or two wavefronts per row with more iterations: no faster)
+    if (nit == 1) hipLaunchKernelGGL(lrcheck16_kernel<1>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
+    else if (nit == 2) hipLaunchKernelGGL(lrcheck16_kernel<2>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
+    else hipLaunchKernelGGL(lrcheck16_kernel<4>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
     return hipGetLastError();
   }
   size_t lds = a.do_lr ? (size_t)g.W * sizeof(unsigned long long) : 0;
