@@ -149,6 +149,30 @@ def test_validate_disparity_matches_numpy(oracle):
     assert np.array_equal(got, np_validate(d4, cost, -4, nd, 1))
 
 
+def test_lr_claim_key_with_the_disparity_picks_cv_winner():
+    """Design claim behind the engine's LR kernel: keying a right-view column's claim by
+    (cost, disparity) selects the same pixel as cv's (cost, then lowest x), because among the claimants of one column
+    x2 = x - round(d/16) a smaller x means a strictly smaller d. Checked on random rows with many cost ties, negative
+    disparities included."""
+    rng = np.random.default_rng(17)
+    for mind in (0, -20, 7):
+        for _ in range(40):
+            w, nd = 120, 48
+            d = (rng.integers(0, nd * 16, w) + mind * 16).astype(np.int64)
+            cost = rng.integers(0, 6, w).astype(np.int64)
+            valid = rng.random(w) < 0.8
+            x = np.arange(w)
+            x2 = x - ((d + 8) >> 4)
+            ok = valid & (x2 >= 0) & (x2 < w)
+            for t in np.unique(x2[ok]):
+                c = np.flatnonzero(ok & (x2 == t))
+                by_x = c[np.lexsort((x[c], cost[c]))][0]            # lowest cost, then lowest x (cv)
+                key = (cost[c] << 16) | ((d[c] & 0xffff) ^ 0x8000)  # the engine's 32-bit claim
+                by_key = c[np.argmin(key)]
+                assert by_x == by_key
+                assert ((int(key.min()) & 0xffff) - 0x8000) == d[by_x]   # and the key carries the winner's disparity
+
+
 def np_speckles(img, new_val, max_size, max_diff):
     """Independent restatement of Appendix A.6 as plain connected components (graph edges between
     4-neighbours that are both valid and within max_diff), via scipy.sparse.csgraph."""
