@@ -279,6 +279,16 @@ def main():
                     "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
                     "stage_ms": {k: round(v, 4) for k, v in prof.items()}, **pmc_extra}
 
+        # the roof that does bound the kernel (SURVEY.md 8d "algorithmic ops"): vector lane-operations per second. Peak = 256 CUs x
+        # 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s with every instruction at full rate; the kernel's v_mqsad_pk_u16_u8
+        # runs at quarter rate, which is why `busy_frac` (VALU busy cycles, from the committed counter run) exceeds `frac`
+        if "lane_ops_per_pixel_disparity" in pmc_extra and kms > 0:
+            lane_ops = pmc_extra["lane_ops_per_pixel_disparity"] * B * W * H * nd
+            peak_lane = 256 * 4 * 16 * 2.4e9
+            roofline["valu"] = {"achieved": round(lane_ops / (kms * 1e-3) / 1e12, 2), "peak": round(peak_lane / 1e12, 1),
+                                "unit": "Tlane-op/s", "frac": round(lane_ops / (kms * 1e-3) / peak_lane, 4),
+                                "busy_frac": pmc_extra.get("valu_busy_frac")}
+
         # the one stage of the path that IS HBM-bound: the prefilter, 1 B read + 1 B written per pixel and image
         pf_ms = prof.get("prefilter", 0.0)
         pf_bytes = 4.0 * W * H * B
