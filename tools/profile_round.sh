@@ -19,8 +19,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_
   --kernel-trace -d "$OUT/pmc_sq2" -o kitti -- $BENCH > "$OUT/bench_sq2.json" 2> "$OUT/sq2.err"
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d "$OUT/pmc_sq3" -o kitti -- $BENCH > "$OUT/bench_sq3.json" 2> "$OUT/sq3.err"
 
-# HBM traffic of the other single-GPU workloads
-for wl in fhd uhd; do
+# HBM traffic of the other single-GPU workloads (ref640 = the reference's own call-site configuration)
+for wl in fhd uhd ref640; do
   WB="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --workload $wl"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/${wl}_pmc_fetch" -o $wl -- $WB > "$OUT/bench_${wl}_fetch.json" 2> "$OUT/${wl}_fetch.err"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/${wl}_pmc_write" -o $wl -- $WB > "$OUT/bench_${wl}_write.json" 2> "$OUT/${wl}_write.err"
@@ -34,7 +34,7 @@ for wl in fhd ref640 uhd; do
   python3 bench.py --workload $wl --check > "$OUT/bench_$wl.json" 2>> "$OUT/plain.err"
 done
 python3 tools/rocprof_summary.py "$OUT" "$OUT/summary" > "$OUT/summary.txt" 2>&1
-for wl in fhd uhd; do   # same summariser on the per-workload counter passes (directories named <wl>_pmc_*)
+for wl in fhd uhd ref640; do   # same summariser on the per-workload counter passes (directories named <wl>_pmc_*)
   mkdir -p "$OUT/$wl"; for d in "$OUT"/${wl}_pmc_*; do ln -sfn "$d" "$OUT/$wl/pmc_$(basename $d | sed "s/${wl}_pmc_//")"; done
   python3 tools/rocprof_summary.py "$OUT/$wl" "$OUT/summary_$wl" >> "$OUT/summary.txt" 2>&1
 done

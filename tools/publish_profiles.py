@@ -32,11 +32,12 @@ def main():
     except Exception:
         commit = "?"
     stamp = datetime.date.today().isoformat()
-    shapes = {"kitti": (1242, 375, 128), "fhd": (1920, 1080, 256), "uhd": (3840, 2160, 256)}
+    shapes = {"kitti": (1242, 375, 128), "fhd": (1920, 1080, 256), "uhd": (3840, 2160, 256), "ref640": (640, 480, 64)}
     tj = {}
     for wl, pmcfile, benchfile, tag in (("kitti", run / "summary_pmc.json", run / "bench_plain.json", f"{rnd}_kitti_b64_pmc.json"),
                                         ("fhd", run / "summary_fhd_pmc.json", run / "bench_fhd.json", f"{rnd}_fhd_pmc.json"),
-                                        ("uhd", run / "summary_uhd_pmc.json", run / "bench_uhd.json", f"{rnd}_uhd_pmc.json")):
+                                        ("uhd", run / "summary_uhd_pmc.json", run / "bench_uhd.json", f"{rnd}_uhd_pmc.json"),
+                                        ("ref640", run / "summary_ref640_pmc.json", run / "bench_ref640.json", f"{rnd}_ref640_pmc.json")):
         if not pmcfile.exists() or not benchfile.exists():
             continue
         pmc = json.loads(pmcfile.read_text())
