@@ -529,6 +529,25 @@ def test_output_buffer_validation(pkg, torch_cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nsub", ["1", "2", "4"])
+@pytest.mark.parametrize("cfg", [(64, 21, 480, 640, 2), (64, 15, 133, 300, 3), (32, 9, 97, 200, 3), (32, 11, 64, 180, 1),
+                                 (48, 13, 77, 260, 2), (16, 5, 50, 120, 4)])
+def test_border_columns_with_packed_row_segments(pkg, oracle, nsub, cfg, monkeypatch):
+    """Border-column kernel with 2 / 4 row segments walked in lockstep by one wavefront (few disparities leave most lanes of a
+    side idle): pre-LR disparity and cost of the clamped-window columns, and everything downstream, against the oracle --
+    heights that leave unpacked remainder segments, every side/segment lane layout."""
+    from u96_slam_amd import synth
+
+    monkeypatch.setenv("SBM_BORDER_NSUB", nsub)
+    nd, wsz, H, W, n = cfg
+    L, R = synth.make_batch(31, n, W, H, nd)
+    kw = dict(num_disparities=nd, block_size=wsz, texture_threshold=10, uniqueness_ratio=10, speckle_window_size=50,
+              speckle_range=32, disp12_max_diff=1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("band", ["0", "2", "4", "8"])
 @pytest.mark.parametrize("shape", [(37, 70, 1), (130, 300, 2), (64, 257, 3), (375, 1242, 2), (201, 515, 40)])
 def test_speckle_band_walk_variants(pkg, oracle, band, shape, monkeypatch):

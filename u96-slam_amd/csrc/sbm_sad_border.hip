@@ -28,6 +28,7 @@ struct BorderArgs {
   int W, H, pitch, padl, plane;
   int nd, mindisp, lofs, rofs, tex, uniq, filtered, capb;
   int row0, row1, seg;
+  int nsub, npacked;   // quad kernel: row segments walked in lockstep by one workgroup; workgroups that do so (full segments only)
   int xo[2];  // first output column (relative to lofs) of the left / right side; each side has w/2 columns
 };
 
@@ -202,29 +203,36 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
   // these wavefronts are latency-bound and share their SIMDs with the VALU-bound interior kernel: let them issue first
   __builtin_amdgcn_s_setprio(3);
   constexpr int NVC = 3 * W2, WSZ = 2 * W2 + 1;
-  constexpr int RPT = 6;                    // staged 8-byte entries per thread per row: 2*(NVC+nd) <= 6*T (host-checked)
+  constexpr int RPT = 6;                    // staged 8-byte entries per thread per row: jobs*(NVC+nd) <= 6*T (host-checked)
   typedef unsigned long long u64;
   const int tid = threadIdx.x, T = blockDim.x;
   const int nq = a.nd >> 2;                 // disparity quads per side
   const int nsl = (NVC + a.nd) / 4 + 2;     // 8-byte entries per residue class of one staged piece
   const int npiece = NVC + a.nd;            // entries of one staged piece (entry p = bytes p .. p+7)
-  // ---- LDS carve-up -------------------------------------------------------------------------------------
-  u64* Rb = reinterpret_cast<u64*>(border_lds);                               // [par][which][side][4*nsl]
-  unsigned short* Sb = reinterpret_cast<unsigned short*>(Rb + 2 * 2 * 2 * 4 * nsl);  // [side][W2][nd]
-  unsigned* Kb = reinterpret_cast<unsigned*>(Sb + 2 * W2 * a.nd);             // [side][W2][nq] local best keys
-  int* Tc = reinterpret_cast<int*>(Kb + 2 * W2 * nq);                         // [side][NVC]
-  unsigned* Best = reinterpret_cast<unsigned*>(Tc + 2 * NVC);                 // [side][W2]
-  int* Tsum = reinterpret_cast<int*>(Best + 2 * W2);                          // [side][W2]
-  int* Hit = Tsum + 2 * W2;                                                   // [side][W2]
-  unsigned char* Lb = reinterpret_cast<unsigned char*>(Hit + 2 * W2);         // [par][which][side][NVC]
+  // Few disparities leave most of a side's 32 lanes idle (nd = 64: 16 of 32), so a workgroup then walks nsub = 2 or 4 row
+  // segments in lockstep: lane group `sub` of each half-wavefront owns segment seg0 + sub. Only full-length segments are
+  // packed (the first a.npacked workgroups); the remaining ones run one per workgroup. A "job" is one (segment, side).
+  const bool packed = (int)blockIdx.x < a.npacked;
+  const int nsub = packed ? a.nsub : 1;
+  const int njobs = 2 * nsub;
+  const int seg0 = packed ? (int)blockIdx.x * a.nsub : a.npacked * a.nsub + ((int)blockIdx.x - a.npacked);
+  const int glanes = 32 / nsub;             // lanes of one job
+  // ---- LDS carve-up (sized on the host for a.nsub) ---------------------------------------------------------
+  u64* Rb = reinterpret_cast<u64*>(border_lds);                               // [par][which][job][4*nsl]
+  unsigned short* Sb = reinterpret_cast<unsigned short*>(Rb + 2 * 2 * njobs * 4 * nsl);  // [job][W2][nd]
+  int* Tc = reinterpret_cast<int*>(Sb + njobs * W2 * a.nd);                   // [job][NVC]
+  unsigned* Best = reinterpret_cast<unsigned*>(Tc + njobs * NVC);             // [job][W2]
+  int* Hit = reinterpret_cast<int*>(Best + njobs * W2);                       // [job][W2]
+  unsigned char* Lb = reinterpret_cast<unsigned char*>(Hit + njobs * W2);     // [par][which][job][NVC]
 
-  // lanes 0..nq-1 = left side, lanes 32..32+nq-1 = right side (nq <= 32, one wavefront): the per-side WTA is a 32-lane
-  // butterfly whatever the disparity count
+  // lanes 0..31 = left side, lanes 32..63 = right side; within a side, lane group sub = (lane & 31) / glanes, quad q
   const int side = (tid >> 5) & 1;
-  const int q = tid & 31;
+  const int sub = (tid & 31) / glanes;
+  const int q = tid & (glanes - 1);
+  const int job = sub * 2 + side;
   const bool act = tid < 64 && q < nq;
-  const int ys = a.row0 + blockIdx.x * a.seg;
-  const int ye = min(ys + a.seg, a.row1);
+  const int ys = a.row0 + seg0 * a.seg;     // first row of segment seg0; segment seg0 + sub starts sub * a.seg rows below
+  const int ye = min(ys + a.seg, a.row1);   // packed segments are full length: ye - ys == a.seg for every sub
   const int pair = blockIdx.y;
   const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl;
   const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl;
@@ -240,62 +248,69 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
     const int ov = a.rofs + clampi(xfirst + v, -a.rofs, a.W - a.rofs - a.nd) - rb0;   // 0 .. NVC-1
     off[v] = ((ov & 3) * nsl + (ov >> 2) + q) * 8;
   }
+  // staging plan of this thread, fixed for the whole segment: RPT right-row entries and 2 left bytes per row. Entry e of
+  // the njobs * npiece right entries belongs to job e / npiece; its source lies (sub * seg) rows below the row of segment
+  // seg0 (offset folded into gofs), its LDS slot is [job][p & 3][p >> 2].
+  int gofs[RPT], lidx[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int e = tid + k * T;
+    gofs[k] = -1; lidx[k] = 0;
+    if (e < njobs * npiece) {
+      const int j = e / npiece, pp = e - j * npiece;
+      gofs[k] = (j >> 1) * a.seg * a.pitch + ((j & 1) ? rb01 : rb00) + pp;
+      lidx[k] = j * 4 * nsl + (pp & 3) * nsl + (pp >> 2);
+    }
+  }
+  int lofs2[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int e = tid + k * T;
+    lofs2[k] = -1;
+    if (e < njobs * NVC) {
+      const int j = e / NVC, v = e - j * NVC;
+      lofs2[k] = (j >> 1) * a.seg * a.pitch + a.lofs + clampi(((j & 1) ? xfirst1 : xfirst0) + v, -a.lofs, a.W - a.lofs - 1);
+    }
+  }
   // vertical sums, packed 4 x u16 per virtual column, in ping-pong (mqsad may not overwrite a source): an entering
   // row maps CA -> CB through the free accumulate, the leaving row maps CB -> CA with plain subtractions
   uint2 CA[NVC];
   u64 CB[NVC];
 #pragma unroll
   for (int v = 0; v < NVC; v++) CA[v] = make_uint2(0u, 0u);
-  int Ct[2] = {0, 0};   // texture: this thread's entries e = tid, tid + T of the 2*NVC (side, virtual column) pairs
+  int Ct[2] = {0, 0};   // texture: this thread's entries e = tid, tid + T of the njobs*NVC (job, virtual column) pairs
 
   struct Staged { u64 r[RPT]; unsigned char l[2]; };
-  auto fetch = [&](int y) {
+  auto fetch = [&](int y) {                 // y: row of segment seg0
     Staged g;
     const uint8_t* lrow = pl + (size_t)y * a.pitch;
     const uint8_t* rrow = pr + (size_t)y * a.pitch;
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int e = tid + k * T;                      // entry index over both sides
       u64 v = 0;
-      if (e < 2 * npiece) {
-        const int sd = e >= npiece, pp = e - sd * npiece;
-        __builtin_memcpy(&v, rrow + (sd ? rb01 : rb00) + pp, 8);
-      }
+      if (gofs[k] >= 0) __builtin_memcpy(&v, rrow + gofs[k], 8);
       g.r[k] = v;
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int e = tid + k * T;
-      unsigned char lv = 0;
-      if (e < 2 * NVC) {
-        const int sd = e >= NVC, v = e - sd * NVC;
-        lv = lrow[a.lofs + clampi((sd ? xfirst1 : xfirst0) + v, -a.lofs, a.W - a.lofs - 1)];
-      }
-      g.l[k] = lv;
-    }
+    for (int k = 0; k < 2; k++) g.l[k] = lofs2[k] >= 0 ? lrow[lofs2[k]] : (unsigned char)0;
     return g;
   };
   auto commit = [&](const Staged& g, int par, int which) {
-    u64* rb = Rb + (size_t)((par * 2 + which) * 2) * 4 * nsl;
-    unsigned char* lb = Lb + ((par * 2 + which) * 2) * NVC;
+    u64* rb = Rb + (size_t)((par * 2 + which) * njobs) * 4 * nsl;
+    unsigned char* lb = Lb + ((par * 2 + which) * njobs) * NVC;
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-      const int e = tid + k * T;
-      if (e < 2 * npiece) {
-        const int sd = e >= npiece, pp = e - sd * npiece;
-        rb[sd * 4 * nsl + (pp & 3) * nsl + (pp >> 2)] = g.r[k];
-      }
-    }
+    for (int k = 0; k < RPT; k++)
+      if (gofs[k] >= 0) rb[lidx[k]] = g.r[k];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
-      if (e < 2 * NVC) lb[e] = g.l[k];     // e = side*NVC + v
+      if (lofs2[k] >= 0) lb[e] = g.l[k];     // e = job*NVC + v
     }
   };
   // mode 0: CB = CA + row (enter)   mode 1: CA = CB - row (leave)   mode 2: CA = CB + row (second of a prime pair)
   auto accumulate = [&](int par, int which, const int mode) {
-    const unsigned char* rbb = reinterpret_cast<const unsigned char*>(Rb + (size_t)((par * 2 + which) * 2 + side) * 4 * nsl);
-    const unsigned char* lb = Lb + ((par * 2 + which) * 2 + side) * NVC;
+    const unsigned char* rbb = reinterpret_cast<const unsigned char*>(Rb + (size_t)((par * 2 + which) * njobs + job) * 4 * nsl);
+    const unsigned char* lb = Lb + ((par * 2 + which) * njobs + job) * NVC;
     if (act) {
 #pragma unroll
       for (int v = 0; v < NVC; v++) {
@@ -313,11 +328,11 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
         }
       }
     }
-    const unsigned char* lall = Lb + ((par * 2 + which) * 2) * NVC;
+    const unsigned char* lall = Lb + ((par * 2 + which) * njobs) * NVC;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
-      if (e < 2 * NVC) {
+      if (lofs2[k] >= 0) {
         const int t = (int)lall[e] - a.capb;
         const int at = t < 0 ? -t : t;
         Ct[k] += mode == 1 ? -at : at;
@@ -353,7 +368,7 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
     accumulate(par, 0, 0);          // CB = window rows y-W2 .. y+W2
 
     // sliding sums over the virtual columns -> W2 outputs, 4 disparities each; publish the sums (sub-pixel lookup) and
-    // reduce the best key over the side's 32 lanes in registers (DPP butterfly + one cross-row exchange)
+    // reduce the best key over the job's lanes in registers (DPP butterfly + one cross-row exchange when a job has 32 lanes)
     u64 S[W2];
     unsigned bestk[W2];
     if (act) {
@@ -363,7 +378,7 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
 #pragma unroll
       for (int j = 0; j < W2; j++) {
         S[j] = ((u64)hi << 32) | lo;
-        *reinterpret_cast<u64*>(Sb + ((size_t)(side * W2 + j) * a.nd + 4 * q)) = S[j];
+        *reinterpret_cast<u64*>(Sb + ((size_t)(job * W2 + j) * a.nd + 4 * q)) = S[j];
         const unsigned d0 = 4u * q;
         const unsigned k0 = (lo << 16) | d0, k1 = (lo & 0xffff0000u) | (d0 + 1);
         const unsigned k2 = (hi << 16) | (d0 + 2), k3 = (hi & 0xffff0000u) | (d0 + 3);
@@ -382,17 +397,19 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       unsigned b = bestk[j];
       b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
       b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x141, 0xf, 0xf, true));  // row_half_mirror
-      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x140, 0xf, 0xf, true));  // row_mirror
-      b = min(b, (unsigned)__shfl_xor((int)b, 16, 64));                               // the other 16-lane row of the side
+      b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x141, 0xf, 0xf, true));  // row_half_mirror: the job's 8 lanes
+      if (glanes >= 16) b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x140, 0xf, 0xf, true));  // row_mirror: 16 lanes
+      if (glanes == 32) b = min(b, (unsigned)__shfl_xor((int)b, 16, 64));             // the other 16-lane row of the side
       bestk[j] = b;
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
-      if (e < 2 * NVC) Tc[e] = Ct[k];
+      if (lofs2[k] >= 0) Tc[e] = Ct[k];
     }
-    // uniqueness: any disparity of the side outside mind-1..mind+1 at or below the threshold (ballot, no LDS round trip)
+    // uniqueness: any disparity of the job outside mind-1..mind+1 at or below the threshold (ballot, no LDS round trip)
+    const int jbase = side * 32 + sub * glanes;                       // first lane of this job
+    const unsigned long long jmask = (glanes == 32 ? 0xffffffffull : ((1ull << glanes) - 1ull)) << jbase;
 #pragma unroll
     for (int j = 0; j < W2; j++) {
       const unsigned best = bestk[j];
@@ -409,25 +426,26 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       }
       const unsigned long long hb = __ballot(hit);
       if (q == 0 && tid < 64) {
-        Best[side * W2 + j] = best;
-        Hit[side * W2 + j] = (int)(((hb >> (32 * side)) & 0xffffffffull) != 0ull);
+        Best[job * W2 + j] = best;
+        Hit[job * W2 + j] = (int)((hb & jmask) != 0ull);
       }
     }
     accumulate(par, 1, 1);          // CA = CB - leaving row (independent of the WTA merge; overlaps its latency)
     par ^= 1;
     __syncthreads();
-    if (tid < 2 * W2) {             // one lane per (side, output column)
-      const int sd = tid / W2, j = tid - sd * W2;
+    if (tid < njobs * W2) {         // one lane per (job, output column)
+      const int jb = tid / W2, j = tid - jb * W2;
+      const int sd = jb & 1, yo = y + (jb >> 1) * a.seg;
       const unsigned best = Best[tid];
       const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
       int ts = 0;
 #pragma unroll
-      for (int v = 0; v < WSZ; v++) ts += Tc[sd * NVC + j + v];
+      for (int v = 0; v < WSZ; v++) ts += Tc[jb * NVC + j + v];
       const bool ok = ts >= a.tex && Hit[tid] == 0;
       int out = a.filtered;
-      const size_t o = (size_t)pair * a.W * a.H + (size_t)y * a.W + a.lofs + a.xo[sd] + j;
+      const size_t o = (size_t)pair * a.W * a.H + (size_t)yo * a.W + a.lofs + a.xo[sd] + j;
       if (ok) {
-        const unsigned short* sb = Sb + (size_t)(sd * W2 + j) * a.nd;
+        const unsigned short* sb = Sb + (size_t)(jb * W2 + j) * a.nd;
         const int p = mind + 1 < a.nd ? sb[mind + 1] : sb[a.nd - 2];
         const int n = mind - 1 >= 0 ? sb[mind - 1] : sb[1];
         const int ad = p > n ? p - n : n - p;
@@ -486,9 +504,23 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   nseg = (rows + a.seg - 1) / a.seg;
   if (version != 1) {
     const int NVC = 3 * g.w2, nq = g.nd / 4, nsl = (NVC + g.nd) / 4 + 2;
-    const size_t lds = (size_t)2 * 2 * 2 * 4 * nsl * 8 + (size_t)2 * g.w2 * g.nd * 2 + (size_t)2 * g.w2 * nq * 4 +
-                       (size_t)2 * NVC * 4 + (size_t)3 * 2 * g.w2 * 4 + (size_t)2 * 2 * 2 * NVC + 16;
-    dim3 grid2(nseg, g.n);
+    // few disparities leave most of a side's 32 lanes idle: pack nsub = 4 / 2 full-length row segments into one workgroup
+    // (limits: lanes, the 6 staged entries and 2 left bytes per thread, one epilogue lane per job and output column).
+    // Throughput regime only -- small batches keep one segment per workgroup (more, shorter workgroups: latency).
+    const int nsub_env = [] { const char* e = getenv("SBM_BORDER_NSUB"); return e ? atoi(e) : 0; }();   // read per call
+    auto fits = [&](int c) { return nq * c <= 32 && 2 * c * (NVC + g.nd) <= 6 * 64 && 2 * c * NVC <= 2 * 64 && 2 * c * g.w2 <= 64; };
+    int nsub = fits(4) ? 4 : fits(2) ? 2 : 1;
+    if ((long)g.n * nseg < 2048) nsub = 1;
+    // SBM_BORDER_NSUB=1|2|4 forces the packing (where it fits) whatever the batch size: tests and A/B runs
+    if ((nsub_env == 1 || nsub_env == 2 || nsub_env == 4) && fits(nsub_env)) nsub = nsub_env;
+    const int full = rows / a.seg;                       // segments of full length
+    a.nsub = nsub;
+    a.npacked = nsub > 1 ? full / nsub : 0;
+    const int nblocks = a.npacked + (nseg - a.npacked * nsub);
+    const int njobs = 2 * nsub;
+    const size_t lds = (size_t)2 * 2 * njobs * 4 * nsl * 8 + (size_t)njobs * g.w2 * g.nd * 2 + (size_t)njobs * NVC * 4 +
+                       (size_t)2 * njobs * g.w2 * 4 + (size_t)2 * 2 * njobs * NVC + 16;
+    dim3 grid2(nblocks, g.n);
     dim3 block2(64 * ((2 * nq + 63) / 64));
 #define SBM_B2(W) case W: hipLaunchKernelGGL(sad_border2_kernel<W>, grid2, block2, lds, s, a); break;
     switch (g.w2) {   // every odd window 5..27
