@@ -33,6 +33,13 @@ struct BorderArgs {
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+typedef unsigned short bu16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bpk_sub_sat(unsigned x, unsigned y) {   // per 16-bit half: max(x - y, 0)
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(bu16x2, x), __builtin_bit_cast(bu16x2, y)));
+}
+__device__ __forceinline__ unsigned bpk_min(unsigned x, unsigned y) {       // per 16-bit half: min(x, y)
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(bu16x2, x), __builtin_bit_cast(bu16x2, y)));
+}
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 #pragma unroll
@@ -246,30 +253,35 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
 #pragma unroll
   for (int v = 0; v < NVC; v++) {
     const int ov = a.rofs + clampi(xfirst + v, -a.rofs, a.W - a.rofs - a.nd) - rb0;   // 0 .. NVC-1
-    off[v] = ((ov & 3) * nsl + (ov >> 2) + q) * 8;
+    off[v] = (__mul24(ov & 3, nsl) + (ov >> 2) + q) * 8;   // (24-bit multiplies: the 32-bit ones run at quarter rate)
   }
   // staging plan of this thread, fixed for the whole segment: RPT right-row entries and 2 left bytes per row. Entry e of
   // the njobs * npiece right entries belongs to job e / npiece; its source lies (sub * seg) rows below the row of segment
   // seg0 (offset folded into gofs), its LDS slot is [job][p & 3][p >> 2].
-  int gofs[RPT], lidx[RPT];
+  unsigned gofs[RPT];                      // byte offset from the row of segment seg0, ~0u: no entry
+  int lidx[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
     const int e = tid + k * T;
-    gofs[k] = -1; lidx[k] = 0;
+    gofs[k] = ~0u; lidx[k] = 0;
     if (e < njobs * npiece) {
-      const int j = e / npiece, pp = e - j * npiece;
-      gofs[k] = (j >> 1) * a.seg * a.pitch + ((j & 1) ? rb01 : rb00) + pp;
-      lidx[k] = j * 4 * nsl + (pp & 3) * nsl + (pp >> 2);
+      int j = 0;                                   // e / npiece without a division (at most 7 jobs to step over)
+      for (int m = 1; m < njobs; m++) j += e >= m * npiece;
+      const int pp = e - __mul24(j, npiece);
+      gofs[k] = (unsigned)(__mul24(j >> 1, a.seg * a.pitch) + ((j & 1) ? rb01 : rb00) + pp);
+      lidx[k] = __mul24(j, 4 * nsl) + __mul24(pp & 3, nsl) + (pp >> 2);
     }
   }
-  int lofs2[2];
+  unsigned lofs2[2];                       // same for the left bytes
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const int e = tid + k * T;
-    lofs2[k] = -1;
+    lofs2[k] = ~0u;
     if (e < njobs * NVC) {
-      const int j = e / NVC, v = e - j * NVC;
-      lofs2[k] = (j >> 1) * a.seg * a.pitch + a.lofs + clampi(((j & 1) ? xfirst1 : xfirst0) + v, -a.lofs, a.W - a.lofs - 1);
+      int j = 0;
+      for (int m = 1; m < njobs; m++) j += e >= m * NVC;
+      const int v = e - j * NVC;
+      lofs2[k] = (unsigned)(__mul24(j >> 1, a.seg * a.pitch) + a.lofs + clampi(((j & 1) ? xfirst1 : xfirst0) + v, -a.lofs, a.W - a.lofs - 1));
     }
   }
   // vertical sums, packed 4 x u16 per virtual column, in ping-pong (mqsad may not overwrite a source): an entering
@@ -288,11 +300,11 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       u64 v = 0;
-      if (gofs[k] >= 0) __builtin_memcpy(&v, rrow + gofs[k], 8);
+      if (gofs[k] != ~0u) __builtin_memcpy(&v, rrow + (size_t)gofs[k], 8);
       g.r[k] = v;
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++) g.l[k] = lofs2[k] >= 0 ? lrow[lofs2[k]] : (unsigned char)0;
+    for (int k = 0; k < 2; k++) g.l[k] = lofs2[k] != ~0u ? lrow[(size_t)lofs2[k]] : (unsigned char)0;
     return g;
   };
   auto commit = [&](const Staged& g, int par, int which) {
@@ -300,11 +312,11 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
     unsigned char* lb = Lb + ((par * 2 + which) * njobs) * NVC;
 #pragma unroll
     for (int k = 0; k < RPT; k++)
-      if (gofs[k] >= 0) rb[lidx[k]] = g.r[k];
+      if (gofs[k] != ~0u) rb[lidx[k]] = g.r[k];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
-      if (lofs2[k] >= 0) lb[e] = g.l[k];     // e = job*NVC + v
+      if (lofs2[k] != ~0u) lb[e] = g.l[k];   // e = job*NVC + v
     }
   };
   // mode 0: CB = CA + row (enter)   mode 1: CA = CB - row (leave)   mode 2: CA = CB + row (second of a prime pair)
@@ -332,7 +344,7 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
-      if (lofs2[k] >= 0) {
+      if (lofs2[k] != ~0u) {
         const int t = (int)lall[e] - a.capb;
         const int at = t < 0 ? -t : t;
         Ct[k] += mode == 1 ? -at : at;
@@ -399,35 +411,58 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
       b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x141, 0xf, 0xf, true));  // row_half_mirror: the job's 8 lanes
       if (glanes >= 16) b = min(b, (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x140, 0xf, 0xf, true));  // row_mirror: 16 lanes
-      if (glanes == 32) b = min(b, (unsigned)__shfl_xor((int)b, 16, 64));             // the other 16-lane row of the side
+      if (glanes == 32) {            // the other 16-lane row of the side: v_permlane16_swap (odd rows of one copy <-> even rows of
+        const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // the other) instead of an LDS-crossbar shuffle
+        b = min(r[0], r[1]);
+      }
       bestk[j] = b;
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int e = tid + k * T;
-      if (lofs2[k] >= 0) Tc[e] = Ct[k];
+      if (lofs2[k] != ~0u) Tc[e] = Ct[k];
     }
-    // uniqueness: any disparity of the job outside mind-1..mind+1 at or below the threshold (ballot, no LDS round trip)
-    const int jbase = side * 32 + sub * glanes;                       // first lane of this job
-    const unsigned long long jmask = (glanes == 32 ? 0xffffffffull : ((1ull << glanes) - 1ull)) << jbase;
+    // uniqueness: "some disparity outside mind-1..mind+1 has a sum <= thresh" <=> the job holds more sums <= thresh than
+    // mind's neighbourhood does. Every lane counts its four packed sums with two saturating packed subtractions; the counts
+    // of four output columns share a register (one byte each: a job's total is at most 128) and are summed over the job's
+    // lanes by the same butterfly as the keys; the epilogue lane, which reads S[mind-1] and S[mind+1] anyway, compares.
+    // (The per-disparity index tests this replaces were 38 % of the kernel's vector instructions.)
+    constexpr int NPK = (W2 + 3) / 4;
+    unsigned pk[NPK];
 #pragma unroll
-    for (int j = 0; j < W2; j++) {
-      const unsigned best = bestk[j];
-      bool hit = false;
-      if (act && a.uniq > 0) {
-        const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
-        const int thresh = minsad + (minsad * a.uniq / 100);
+    for (int i = 0; i < NPK; i++) pk[i] = 0;
+    if (a.uniq > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int d = 4 * q + i;
-          const int sv = (int)((S[j] >> (16 * i)) & 0xffffu);
-          hit |= (d < mind - 1 || d > mind + 1) && sv <= thresh;
-        }
+      for (int j = 0; j < W2; j++) {
+        // minsad * uniq / 100 with a 24-bit multiply and one mulhi (x / 100 == mulhi(x, 0x51EB851F) >> 5 for 32-bit x); the
+        // plain expression costs two quarter-rate 32-bit multiplies per output column. The envelope keeps the product < 2^23.
+        const unsigned minsad = bestk[j] >> 16;
+        const unsigned thresh = minsad + (__umulhi(__umul24(minsad, (unsigned)a.uniq), 0x51EB851Fu) >> 5);
+        const unsigned Tq = min(thresh + 1u, 65535u);                  // sums are <= 65534: sv <= thresh <=> Tq - sv > 0
+        const unsigned T2 = Tq | (Tq << 16);
+        const unsigned c2 = bpk_min(bpk_sub_sat(T2, (unsigned)S[j]), 0x00010001u) +
+                            bpk_min(bpk_sub_sat(T2, (unsigned)(S[j] >> 32)), 0x00010001u);   // 0..2 per 16-bit half
+        pk[j >> 2] |= ((c2 & 0xffffu) + (c2 >> 16)) << (8 * (j & 3));  // 0..4 (idle lanes hold 0xffff sums: 0)
       }
-      const unsigned long long hb = __ballot(hit);
-      if (q == 0 && tid < 64) {
-        Best[job * W2 + j] = best;
-        Hit[job * W2 + j] = (int)((hb & jmask) != 0ull);
+#pragma unroll
+      for (int i = 0; i < NPK; i++) {
+        unsigned b = pk[i];
+        b += (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xf, 0xf, true);
+        b += (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x4E, 0xf, 0xf, true);
+        b += (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x141, 0xf, 0xf, true);
+        if (glanes >= 16) b += (unsigned)__builtin_amdgcn_mov_dpp((int)b, 0x140, 0xf, 0xf, true);
+        if (glanes == 32) {
+          const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+          b = r[0] + r[1];
+        }
+        pk[i] = b;
+      }
+    }
+    if (q == 0 && tid < 64) {
+#pragma unroll
+      for (int j = 0; j < W2; j++) {
+        Best[job * W2 + j] = bestk[j];
+        Hit[job * W2 + j] = (int)((pk[j >> 2] >> (8 * (j & 3))) & 0xffu);
       }
     }
     accumulate(par, 1, 1);          // CA = CB - leaving row (independent of the WTA merge; overlaps its latency)
@@ -441,16 +476,29 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       int ts = 0;
 #pragma unroll
       for (int v = 0; v < WSZ; v++) ts += Tc[jb * NVC + j + v];
-      const bool ok = ts >= a.tex && Hit[tid] == 0;
+      const unsigned short* sb = Sb + (size_t)(jb * W2 + j) * a.nd;
+      const int p = mind + 1 < a.nd ? sb[mind + 1] : sb[a.nd - 2];
+      const int n = mind - 1 >= 0 ? sb[mind - 1] : sb[1];
+      bool ok = ts >= a.tex;
+      if (a.uniq > 0) {
+        const int tl = min(minsad + (minsad * a.uniq / 100), 65534);
+        const int expected = 1 + (mind + 1 < a.nd && p <= tl) + (mind - 1 >= 0 && n <= tl);   // of mind-1, mind, mind+1
+        ok = ok && Hit[tid] == expected;
+      }
       int out = a.filtered;
       const size_t o = (size_t)pair * a.W * a.H + (size_t)yo * a.W + a.lofs + a.xo[sd] + j;
       if (ok) {
-        const unsigned short* sb = Sb + (size_t)(jb * W2 + j) * a.nd;
-        const int p = mind + 1 < a.nd ? sb[mind + 1] : sb[a.nd - 2];
-        const int n = mind - 1 >= 0 ? sb[mind - 1] : sb[1];
         const int ad = p > n ? p - n : n - p;
         const int den = p + n - 2 * minsad + ad;
-        out = ((a.nd - mind - 1 + a.mindisp) * 256 + (den != 0 ? (p - n) * 256 / den : 0) + 15) >> 4;
+        int frac = 0;
+        if (den != 0) {               // |p-n|*256 < 2^24: the float estimate is within 1 of the quotient (C division truncates)
+          const unsigned num = (unsigned)ad << 8;
+          unsigned qv = (unsigned)((float)num / (float)den);
+          while ((unsigned long long)qv * (unsigned)den > num) qv--;
+          while ((unsigned long long)(qv + 1) * (unsigned)den <= num) qv++;
+          frac = p >= n ? (int)qv : -(int)qv;
+        }
+        out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
         if (a.cost) {
           if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)minsad;
           else static_cast<int32_t*>(a.cost)[o] = minsad;
