@@ -157,20 +157,28 @@ __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
     const int x0 = 4 * (threadIdx.x + BS * k);
     if (x0 >= W) return;
     short res[4];
+    // targets x - floor(d/16) and x - ceil(d/16): the same column or two adjacent ones -> one two-word read. A pixel that
+    // is not checked, or whose floor target lies outside the row, reads "no claimant" twice (it cannot fail then: both
+    // targets must disagree); a ceil target of -1 reads the front pad. All four reads are issued before the first use, and the
+    // verdict is plain arithmetic (no short-circuit: a branch per pixel would serialise the four LDS latencies).
+    unsigned k0[4], k1[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int x = x0 + i;
       const int d = dv[k][i];
-      // targets x - floor(d/16) and x - ceil(d/16): the same column or two adjacent ones -> one two-word read. A pixel that
-      // is not checked, or whose floor target lies outside the row, reads "no claimant" twice (it cannot fail then: both
-      // targets must disagree); a ceil target of -1 reads the front pad.
       const int xa = x - (d >> 4);
-      const bool checked = d != INV && (IN || (x >= minX1 && x < maxX1)) && (unsigned)xa < (unsigned)W;
+      const bool checked = ((int)(d != INV) & (int)(IN || (x >= minX1 && x < maxX1)) & (int)((unsigned)xa < (unsigned)W)) != 0;
       const int p = checked ? xa : W + 1;
-      const unsigned k0 = key[p], k1 = key[p + 1];          // claims of columns xa-1, xa
-      const unsigned ka = k1, kb = (d & 15) ? k0 : k1;
+      k0[i] = key[p];            // claim of column xa-1
+      k1[i] = key[p + 1];        // claim of column xa
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int x = x0 + i;
+      const int d = dv[k][i];
+      const unsigned ka = k1[i], kb = (d & 15) ? k0[i] : k1[i];
       const int da = (int)(ka & 0xffffu) - 0x8000, db = (int)(kb & 0xffffu) - 0x8000;
-      const bool bad = ka < 0xffff0000u && kb < 0xffff0000u && abs(da - d) > a.tol && abs(db - d) > a.tol;
+      const bool bad = ((int)(max(ka, kb) < 0xffff0000u) & (int)(min(abs(da - d), abs(db - d)) > a.tol)) != 0;
       res[i] = (short)(((!IN && (x < a.col0 || x >= a.col1)) || bad) ? INV : d);
     }
     if (IN || x0 + 4 <= W) {
