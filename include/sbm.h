@@ -134,6 +134,8 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
  * enabled = 1: every sbm_compute_device call synchronises and sbm_get_profile returns the LAST call's times;
  * enabled = 2: events are recorded without synchronising (use inside a timed region) and sbm_get_profile
  *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
+ * enabled = 3: as 2, but only every 4th call is instrumented (the six event records cost ~25 us per call at the bench size;
+ *              sampling keeps a timed region close to the un-instrumented rate).
  * names: "prefilter", "sad" (fast SAD/WTA kernel; every SAD launch of the call when it is pipelined), "border" (what
  * is left of the border-column kernel after the interior kernel has finished; the generic kernel when the fast path
  * is off), "lrcheck", "speckle", "total". */

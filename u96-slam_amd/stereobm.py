@@ -476,7 +476,8 @@ class StereoBM:
         return self._L.sbm_stream(self._h)
 
     def set_profiling(self, on):
-        # 0 = off, 1 = sync after every call, 2 = stage events only (no host sync; up to 64 calls per profile() read)
+        # 0 = off, 1 = sync after every call, 2 = stage events only (no host sync; up to 64 calls per profile() read),
+        # 3 = as 2 on every 4th call only
         _check(self._L.sbm_set_profiling(self._h, int(on)), self._h)
 
     def profile(self):
