@@ -476,9 +476,12 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   const int strips = (a.xc1 - a.xc0 + nv - 1) / nv;
   const int rows = g.row1 - g.row0;
   // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
-  // segment at ~1/3 of a full row's cost) below ~10 %
+  // segment at ~1/3 of a full row's cost) below ~10 %. The target is tuned on the length of the whole SAD stage, interior
+  // kernel + what remains of the border kernel after it: fewer, longer interior workgroups cost the interior kernel ~1 %
+  // but let the border kernel finish earlier (KITTI x64, 4 instead of 6 segments: 1.100 + 0.053 -> 1.115 + 0.028 ms;
+  // tools/exp/r02_target.sh: 5600 is never worse than 9000 or 4500 on any of the bench workloads)
   int nseg = 1;
-  static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 9000L; }();
+  static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 5600L; }();
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
   // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
   // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
