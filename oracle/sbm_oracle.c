@@ -133,7 +133,7 @@ void sbmo_find_correspondence(const uint8_t* left_full, const uint8_t* right_ful
   const int rofs = -imin(ndisp - 1 + mindisp, 0);
   const int width1 = width - rofs - ndisp + 1;
   const int ftzero = p->prefilter_cap;
-  const int16_t FILTERED = (int16_t)((mindisp - 1) << 4);
+  const int16_t FILTERED = (int16_t)((mindisp - 1) * 16);   /* (cv writes (minDisparity - 1) << 4; a negative left shift is UB in C) */
 
   const uint8_t* lbase = left_full + (size_t)row0 * stride + lofs;
   const uint8_t* rbase = right_full + (size_t)row0 * stride + rofs;
@@ -270,7 +270,7 @@ void sbmo_find_correspondence_bruteforce(const uint8_t* left_full, const uint8_t
   const int lofs = imax(ndisp - 1 + mindisp, 0), rofs = -imin(ndisp - 1 + mindisp, 0);
   const int width1 = width - rofs - ndisp + 1;
   const int cap = p->prefilter_cap;
-  const int16_t FILTERED = (int16_t)((mindisp - 1) << 4);
+  const int16_t FILTERED = (int16_t)((mindisp - 1) * 16);   /* (cv writes (minDisparity - 1) << 4; a negative left shift is UB in C) */
   const int dy0 = imin(row0, wsz2 + 1), dy1 = imin(height_full - row1, wsz2 + 1);
   const int ylo = row0 - dy0, yhi = row1 + dy1 - 1; /* rows the stripe may read */
   int* sad = (int*)malloc(sizeof(int) * (size_t)(ndisp + 2));
@@ -518,7 +518,7 @@ int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const
     return SBM_ERR_SIZE;
   const size_t dstride = dstride_bytes / 2;
   const int mindisp = p->min_disparity, ndisp = p->num_disparities;
-  const int16_t FILTERED = (int16_t)((mindisp - 1) << 4);
+  const int16_t FILTERED = (int16_t)((mindisp - 1) * 16);   /* (cv writes (minDisparity - 1) << 4; a negative left shift is UB in C) */
   const int lofs = imax(ndisp - 1 + mindisp, 0), rofs = -imin(ndisp - 1 + mindisp, 0);
   const int width1 = width - rofs - ndisp + 1;
   const size_t npix = (size_t)width * height;
