@@ -95,6 +95,12 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
 // This kernel is bound by VALU issue (about 40 instructions per pixel slot), not by memory.
 extern __shared__ __attribute__((aligned(16))) unsigned lr_lds32[];
 
+__device__ __forceinline__ unsigned absdiff_u32(unsigned x, unsigned y) {   // |x - y|: v_sad_u32 with a zero accumulator
+  unsigned r;
+  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
 template <int NIT>
 __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
   const int BS = blockDim.x;   // 64..256 threads (a multiple of 64): narrow rows get a narrower block
@@ -177,8 +183,10 @@ __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
       const int x = x0 + i;
       const int d = dv[k][i];
       const unsigned ka = k1[i], kb = (d & 15) ? k0[i] : k1[i];
-      const int da = (int)(ka & 0xffffu) - 0x8000, db = (int)(kb & 0xffffu) - 0x8000;
-      const bool bad = ((int)(max(ka, kb) < 0xffff0000u) & (int)(min(abs(da - d), abs(db - d)) > a.tol)) != 0;
+      // |winner's disparity - d| on the biased 16-bit values, one v_sad_u32 per target
+      const unsigned db16 = (unsigned)(d + 0x8000);
+      const unsigned ea = absdiff_u32(ka & 0xffffu, db16), eb = absdiff_u32(kb & 0xffffu, db16);
+      const bool bad = ((int)(max(ka, kb) < 0xffff0000u) & (int)(min(ea, eb) > (unsigned)a.tol)) != 0;
       res[i] = (short)(((!IN && (x < a.col0 || x >= a.col1)) || bad) ? INV : d);
     }
     if (IN || x0 + 4 <= W) {
