@@ -14,10 +14,24 @@ sys.path.insert(0, str(ROOT / "tests"))
 sys.path.insert(0, str(ROOT / "oracle"))
 
 
+def make_bm(pkg, kw):
+    bm = pkg.StereoBM.create(kw.get("num_disparities", 64), kw.get("block_size", 21))
+    setters = dict(prefilter_cap=bm.setPreFilterCap, min_disparity=bm.setMinDisparity, texture_threshold=bm.setTextureThreshold,
+                   uniqueness_ratio=bm.setUniquenessRatio, speckle_window_size=bm.setSpeckleWindowSize,
+                   speckle_range=bm.setSpeckleRange, disp12_max_diff=bm.setDisp12MaxDiff, prefilter_type=bm.setPreFilterType,
+                   prefilter_size=bm.setPreFilterSize)
+    for k, v in kw.items():
+        if k in setters:
+            setters[k](v)
+    return bm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="frame-sized images and batches up to 48 pairs (the band walk's 4-row "
+                    "bands, multi-iteration LR rows, packed border segments); a few hundred iterations take minutes")
     args = ap.parse_args()
     import numpy as np
     import _pkg
@@ -37,6 +51,10 @@ def main():
         h = int(rng.integers(wsz + 8, wsz + 90))
         lo = max(nd + abs(mind), 0) + 2 * wsz + 8
         w = int(rng.integers(lo, lo + 300))
+        if args.big:
+            n = int(rng.choice([1, 4, 12, 24, 48]))
+            h = int(rng.integers(180, 520))
+            w = int(rng.integers(max(lo, 600), 1400))
         kw = dict(num_disparities=nd, block_size=wsz, min_disparity=mind, prefilter_cap=int(rng.choice([31, 31, 15, 63, 1, 40])),
                   texture_threshold=int(rng.choice([0, 10, 10, 200, 1000])), uniqueness_ratio=int(rng.choice([0, 5, 10, 15, 40, 90])),
                   disp12_max_diff=int(rng.choice([-1, 0, 1, 1, 3])))
@@ -51,17 +69,32 @@ def main():
         if n == 1 and rng.random() < 0.5:
             L, R = L[0], R[0]
         try:
-            eng, ref = run_engine(pkg, oracle, kw, L, R)
-            assert_stages_equal(eng, ref, kw)
-            eng2, _ = run_engine(pkg, oracle, kw, L, R, stages=False)
-            assert np.array_equal(eng2["disp"], eng["disp"]), "second run differs"
+            if args.big and n >= 16:
+                # the host entry point pipelines batches of >= 16 pairs in chunks (the per-stage planes then belong to the
+                # last chunk only): check its final maps, then run the whole batch as ONE device call and check every stage
+                eng, ref = run_engine(pkg, oracle, kw, L, R, stages=False)
+                assert np.array_equal(eng["disp"].reshape(ref["disp"].shape), ref["disp"]), "final disparity differs (host, pipelined)"
+                import torch
+
+                bm = make_bm(pkg, kw)
+                dd = bm.compute_device(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+                dev = dict(disp=dd.cpu().numpy().reshape(n, h, w), pf_l=bm.debug_fetch(0, n, h, w), pf_r=bm.debug_fetch(1, n, h, w),
+                           pre_lr=bm.debug_fetch(3, n, h, w))
+                if kw.get("disp12_max_diff", -1) >= 0:
+                    dev["cost"] = bm.debug_fetch(2, n, h, w)
+                assert_stages_equal(dev, ref, kw)
+            else:
+                eng, ref = run_engine(pkg, oracle, kw, L, R)
+                assert_stages_equal(eng, ref, kw)
+                eng2, _ = run_engine(pkg, oracle, kw, L, R, stages=False)
+                assert np.array_equal(eng2["disp"], eng["disp"]), "second run differs"
         except AssertionError as e:
             bad.append({"iteration": it, "shape": [n, h, w], "params": kw, "error": str(e)[:200]})
     # ---- the reference's own PL blocks (FPGA-flavour matcher, GFTT map): random sizes / windows / phases / filter settings
     import torch
 
     bmf = pkg.StereoBM.create(64, 21)
-    nf = max(10, args.iters // 4)
+    nf = 0 if args.big else max(10, args.iters // 4)
     for it in range(nf):
         wsz = int(rng.choice([3, 5, 9, 15, 21, 27, 31]))
         nd = int(rng.choice([32, 64, 96, 128, 192, 256]))
