@@ -529,6 +529,22 @@ def test_output_buffer_validation(pkg, torch_cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(40, 4200, 64, 9, 2), (33, 5000, 128, 15, 1), (60, 4097, 32, 5, 3), (48, 4096, 64, 21, 2)])
+def test_rows_wider_than_4096(pkg, oracle, cfg):
+    """Rows at and beyond the 4096-column limit of the 16-bit LR kernel (the generic LR kernel takes over, with the 16-bit cost
+    plane of the fast SAD kernels), with every post-filter on."""
+    h, w, nd, wsz, n = cfg
+    rng = np.random.default_rng(5)
+    pairs = [rand_pair(rng, h, w, shift=7, noise=3) for _ in range(n)]
+    L = np.stack([p[0] for p in pairs]); R = np.stack([p[1] for p in pairs])
+    kw = dict(num_disparities=nd, block_size=wsz, texture_threshold=10, uniqueness_ratio=10, speckle_window_size=50,
+              speckle_range=32, disp12_max_diff=1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+    assert (eng["disp"] >= 0).mean() > 0.3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nsub", ["1", "2", "4"])
 @pytest.mark.parametrize("cfg", [(64, 21, 480, 640, 2), (64, 15, 133, 300, 3), (32, 9, 97, 200, 3), (32, 11, 64, 180, 1),
                                  (48, 13, 77, 260, 2), (16, 5, 50, 120, 4)])
