@@ -19,6 +19,10 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_
   --kernel-trace -d "$OUT/pmc_sq2" -o kitti -- $BENCH > "$OUT/bench_sq2.json" 2> "$OUT/sq2.err"
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d "$OUT/pmc_sq3" -o kitti -- $BENCH > "$OUT/bench_sq3.json" 2> "$OUT/sq3.err"
 
+# kernel trace of the reference's own call-site configuration (640x480, nd 64, 21x21)
+mkdir -p "$OUT/ref640t"
+rocprofv3 --kernel-trace --stats -d "$OUT/ref640t/trace" -o ref640 -- $BENCH --workload ref640 > "$OUT/bench_ref640_trace.json" 2> "$OUT/ref640_trace.err"
+
 # HBM traffic of the other single-GPU workloads (ref640 = the reference's own call-site configuration)
 for wl in fhd uhd ref640; do
   WB="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --workload $wl"
@@ -38,5 +42,6 @@ for wl in fhd uhd ref640; do   # same summariser on the per-workload counter pas
   mkdir -p "$OUT/$wl"; for d in "$OUT"/${wl}_pmc_*; do ln -sfn "$d" "$OUT/$wl/pmc_$(basename $d | sed "s/${wl}_pmc_//")"; done
   python3 tools/rocprof_summary.py "$OUT/$wl" "$OUT/summary_$wl" >> "$OUT/summary.txt" 2>&1
 done
+python3 tools/rocprof_summary.py "$OUT/ref640t" "$OUT/summary_ref640t" >> "$OUT/summary.txt" 2>&1
 tail -n 40 "$OUT/summary.txt"
 cat "$OUT"/bench_plain.json

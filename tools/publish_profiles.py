@@ -20,6 +20,8 @@ def main():
     prof = Path(__file__).resolve().parents[1] / "profiles"
     shutil.copy(run / "summary_kernels.md", prof / f"{rnd}_kitti_b64_kernels.md")
     shutil.copy(run / "summary_pmc.json", prof / f"{rnd}_kitti_b64_pmc.json")
+    if (run / "summary_ref640t_kernels.md").exists():
+        shutil.copy(run / "summary_ref640t_kernels.md", prof / f"{rnd}_ref640_b64_kernels.md")
     for src, dst in (("plain", "plain"), ("trace", "trace"), ("fhd", "fhd"), ("ref640", "ref640"), ("uhd", "uhd")):
         f = run / f"bench_{src}.json"
         if f.exists():
