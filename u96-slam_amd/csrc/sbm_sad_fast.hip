@@ -30,11 +30,28 @@
 
 #include "sbm_common.h"
 
+// SBM_ABL=n (development builds only, tools/exp/r03_ablate.sh): leave one phase of the row loop out to measure its
+// marginal cost on the GPU; results are wrong by construction.
+#ifndef SBM_ABL
+#define SBM_ABL 0
+#endif
+#ifndef SBM_FAST_PINGPONG
+#define SBM_FAST_PINGPONG 0
+#endif
+
+#if SBM_FAST_PINGPONG   // second build of this file (sbm_sad_fast_pp.hip): same kernels with two accumulator arrays
+#define sad_fast_kernel sad_fast_pp_kernel
+#define launch_sad_fast launch_sad_fast_pp
+#define FastArgs FastArgsPP
+#define fast_lds fast_pp_lds
+#endif
+
 namespace sbm {
 
 typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct FastArgs {
   const uint8_t* pf_l;
@@ -81,8 +98,22 @@ extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NS
 // NDW disparities per wavefront, NWAVES wavefronts per workgroup covering NDW*NWAVES >= nd disparities of the SAME
 // 64 columns.  NWAVES > 1 keeps the register footprint of a wavefront at NDW/2 accumulators + NDW/2 sums (4 waves per
 // SIMD at NDW = 64) at the price of two workgroup barriers per row for the WTA merge through LDS.
+#if SBM_FAST_PINGPONG
+#define SBM_FAST_WAVES_PER_EU
+#else
+// wavefronts per SIMD the register allocation aims at: 5 for the cooperating 64-disparity wavefronts (their two barriers
+// per row want the extra wavefront to cover the waits), 4 for a lone wavefront (no barriers: measured slower at 5),
+// 3 for the 128-disparity single-wavefront variant
+#define SBM_FAST_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(NDW > 64 ? 3 : (NWAVES > 1 ? SBM_FAST_WPE : SBM_FAST_WPE1))))
+#ifndef SBM_FAST_WPE
+#define SBM_FAST_WPE 5
+#endif
+#ifndef SBM_FAST_WPE1
+#define SBM_FAST_WPE1 4
+#endif
+#endif
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND>
-__global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
+__global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_kernel(FastArgs a) {
   constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
   constexpr int NR = NDW / 2;           // packed pair registers
   constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
@@ -130,9 +161,14 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
   const int ys = a.segrow[segi];
   const int ye = a.segrow[segi + 1];
-  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + c;  // left bytes of this lane
+  // wavefront-uniform bases (scalar registers; the per-row step is scalar arithmetic) + this lane's 32-bit offset
+  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + strip * NV;  // left bytes: + lane
   // right piece of the wavefront: window of buffer index d starts at rofs + c + d
   const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + strip * NV + d0;
+  const unsigned lane_u = (unsigned)lane;
+  // raw buffer descriptors over the rest of this pair's planes (rows of one pair are < 2^31 bytes apart)
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pl), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pr), 0, 0x7fffffff, 0x00020000);
   // LDS carve-up (16-byte units): per wavefront one region of WSLOT slots that serves first as the staging area of a
   // row (apply) and then as the exchange area of the horizontal window -- never live together, and a wavefront's LDS
   // operations execute in order -- followed by the WTA merge area of the workgroup.
@@ -144,13 +180,24 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   uint2* const xacc = reinterpret_cast<uint2*>(xkey + 2 * NWAVES * 64); // [2][NWAVES][64]  (deficit acc, nn | pp<<16)
   const u32 capw = (u32)a.capb * 0x01010101u;
 
-  // packed 4 x u16 per quad (low dword = indices 4q,4q+1, high dword = 4q+2,4q+3).  Two arrays in ping-pong:
-  // v_mqsad_pk_u16_u8 may not write a register it reads, so an entering row maps VA -> VB through the
-  // instruction's free accumulate and the leaving row maps VB -> VA with plain subtractions.
+  // packed 4 x u16 per quad (low dword = indices 4q,4q+1, high dword = 4q+2,4q+3).
+#if SBM_FAST_PINGPONG
+  // Two arrays in ping-pong: the compiler never lets v_mqsad_pk_u16_u8 write a register it reads (vdst is early-clobber
+  // against every source in LLVM), so an entering row maps VA -> VB through the instruction's free accumulate and the
+  // leaving row maps VB -> VA with plain subtractions.
   uint2 VA[NQ];
   u64 VB[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) VA[q] = make_uint2(0u, 0u);
+#else
+  // ONE array, accumulated in place: on gfx950 the instruction gives the right result when vdst is its own accumulator
+  // (src2) -- verified on the device by tools/ubench/mqsad_alias (9.4e9 results) and re-checked by
+  // sbm_selftest_mqsad_inplace() when a handle is created (the ping-pong build of this kernel, sbm_sad_fast_pp.hip, is
+  // the fallback). That frees 32 VGPRs: 5 wavefronts per SIMD instead of 4.
+  u64 VB[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) VB[q] = 0ull;
+#endif
   u32 Vt = 0;  // texture: window-row sum of the 3-column |L - cap|
 
   // One row of one image contributes in three phases, split so that global-load latency overlaps compute:
@@ -160,10 +207,15 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
   struct RowRegs { uint4 r[NIT]; u32 l; };
   auto fetch = [&](int y) {
     RowRegs g;
-    const uint8_t* rrow = pr + (size_t)y * a.pitch;
+    // buffer loads: descriptor base + this lane's 32-bit offset + the row offset in a scalar register, so a row
+    // costs no vector address arithmetic (flat 64-bit addressing cost two v_mad_u64_u32 per fetch)
+    const int rowoff = __builtin_amdgcn_readfirstlane(y * a.pitch);
 #pragma unroll
-    for (int it = 0; it < NIT; it++) g.r[it] = load_u128_unaligned(rrow + it * 64 + lane);
-    g.l = load_u32_ua(pl + (size_t)y * a.pitch);
+    for (int it = 0; it < NIT; it++) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(it * 64 + lane_u), rowoff, 0);
+      g.r[it] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    g.l = __builtin_amdgcn_raw_buffer_load_b32(rs_l, (int)lane_u, rowoff, 0);
     return g;
   };
   // mode 0: VB = VA + row (enter)   mode 1: VA = VB - row (leave)   mode 2: VA = VB + row (second half of a prime pair)
@@ -200,6 +252,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
           hi = ((qq - 1) & 2) ? v.w : v.y;
         }
         const u64 win = ((u64)hi << 32) | lo;
+#if SBM_FAST_PINGPONG
         if (mode == 0) {
           VB[q] = __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, __builtin_bit_cast(u64, VA[q]));
         } else if (mode == 2) {
@@ -210,6 +263,17 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
           VA[q].x = vb.x - tt.x;                                // no u16 lane borrows: every partial sum is exact
           VA[q].y = vb.y - tt.y;
         }
+#else
+        if (mode != 1) {
+          asm("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(VB[q]) : "v"(win), "v"(pat));
+        } else {
+          const uint2 tt = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull));
+          uint2 vb = __builtin_bit_cast(uint2, VB[q]);
+          vb.x -= tt.x;                                         // no u16 lane borrows: every partial sum is exact
+          vb.y -= tt.y;
+          VB[q] = __builtin_bit_cast(u64, vb);
+        }
+#endif
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -226,7 +290,10 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
     g = n2;
   }
   // g now holds row ys+W2
-  const size_t obase = (size_t)pair * a.W * a.H + a.lofs + xc;
+  // outputs through buffer stores as well: per-pair descriptors, this lane's byte offset, the row in a scalar register
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.disp + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a.cost + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
+  const int ocol = 2 * (a.lofs + xc);
   for (int y = ys; y < ye; y++) {
     apply(g, 0);
 
@@ -238,7 +305,12 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
     // Lanes >= NV read beyond lane 63 (unwritten halo entries): their sums are garbage and never stored.
     u32 S[NR];
     const int par = y & 1;
+    const int orow = __builtin_amdgcn_readfirstlane(2 * y * a.W);
     xt[lane] = Vt;
+#if SBM_ABL == 4
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { const uint2 v = __builtin_bit_cast(uint2, VB[q]); S[2 * q] = v.x; S[2 * q + 1] = v.y; }
+#else
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += XCH) {
       // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
@@ -268,6 +340,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+#endif
     if constexpr (!EXACT_ND) {
 #pragma unroll
       for (int j = 0; j < NR; j++)
@@ -278,6 +351,14 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
     // keys carry a group-local index 0..63 (inline constants for v_lshl_or_b32 / v_and_or_b32); the group base is
     // added once per group.  Four independent v_min3_u32 chains per group keep the dependency chains short.
     u32 best = 0xffffffffu;
+#if SBM_ABL == 3
+    {
+      u32 f = 0;
+#pragma unroll
+      for (int j = 0; j < NR; j += 8) f ^= S[j];
+      best = ((f & 0x3fffu) << 16) | ((f >> 16) & 63u);
+    }
+#else
 #pragma unroll
     for (int g0 = 0; g0 < NR; g0 += 32) {
       u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -290,6 +371,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
       const u32 bg = min(min(b[0], b[1]), min(b[2], b[3])) + (u32)(2 * g0);
       best = min(best, bg);
     }
+#endif
     best += (u32)d0;
     const int mpar = par * NWAVES * 64;   // the merge arrays alternate by row parity
     if constexpr (NWAVES > 1) {
@@ -306,19 +388,34 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
       const int thresh = minsad + (minsad * a.uniq / 100);
       T = (u32)min(thresh + 1, 65535);
       const u32 T2 = T | (T << 16);
-      // four independent accumulators (a single chain is one dependent v_pk_sub -> v_pk_add pair per register with a
-      // wait state in between). Every deficit is at most T - minsad <= maxS*uniq/100 + 1; when NR/4 of them cannot
-      // reach 65536 (host check, uniq_plain) the partial sums are plain 32-bit adds of the packed halves -- no carry
-      // can cross -- and only the final combine saturates. Saturating adds give min(65535, sum) in any grouping.
-      u32 ac[4] = {0u, 0u, 0u, 0u};
-      if (NR <= 32 && a.uniq_plain) {
+      // independent accumulators of 8 registers each (a single chain is one dependent v_pk_sub -> v_pk_add pair per
+      // register with a wait state in between). Every deficit is at most T - minsad <= maxS*uniq/100 + 1; when 8 of them
+      // cannot reach 65536 (host check, uniq_plain) the partial sums are plain 32-bit adds of the packed halves -- no
+      // carry can cross -- and only the final combine saturates. Saturating adds give min(65535, sum) in any grouping.
+      constexpr int NACC = NR >= 32 ? NR / 8 : 4;
+      u32 ac[NACC];
 #pragma unroll
-        for (int j = 0; j < NR; j++) ac[j & 3] += pk_sub_sat(T2, S[j]);
+      for (int k = 0; k < NACC; k++) ac[k] = 0u;
+#if SBM_ABL == 2
+      ac[0] = S[0] ^ S[NR - 1] ^ T2;
+#else
+      if (a.uniq_plain) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) ac[j % NACC] += pk_sub_sat(T2, S[j]);
       } else {
+        // (an opaque copy of the threshold: otherwise the compiler hoists the NR subtractions both paths share above
+        // the branch and keeps all of them live at once -- 32 registers at the kernel's pressure peak)
+        u32 T2s = T2;
+        asm("" : "+v"(T2s));
 #pragma unroll
-        for (int j = 0; j < NR; j++) ac[j & 3] = pk_add_sat(ac[j & 3], pk_sub_sat(T2, S[j]));
+        for (int j = 0; j < NR; j++) ac[j % NACC] = pk_add_sat(ac[j % NACC], pk_sub_sat(T2s, S[j]));
       }
-      acc = pk_add_sat(pk_add_sat(ac[0], ac[1]), pk_add_sat(ac[2], ac[3]));
+#endif
+#pragma unroll
+      for (int n = NACC; n > 1; n >>= 1)
+#pragma unroll
+        for (int k = 0; k < n / 2; k++) ac[k] = pk_add_sat(ac[k], ac[k + n / 2]);
+      acc = ac[0];
     }
 
     // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
@@ -329,15 +426,22 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
     // byte selectors built arithmetically from the packed index pair (compares + selects cost several times as much):
     // low half of every selector follows ln, high half lp
     const u32 lnp = (u32)ln | ((u32)lp << 16);
+#if SBM_ABL == 1
+    X[0] = (S[0] ^ S[NR - 1] ^ lnp) & 0x3fff3fffu;
+#else
     {
       // bytes (2a, 2a+1) with a = index & 3:  0x0100 + a * 0x0202 per half
       const u32 sel = __umul24(lnp & 0x00030003u, 0x0202u) + 0x01000100u;
 #pragma unroll
       for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
     }
+#endif
     // S is dead from here on: fetch the leaving row now (its latency hides behind the rest of the tree, the
     // merge, the sub-pixel arithmetic and the stores) without raising the register peak of the S-heavy phase
+#if SBM_ABL != 5
     RowRegs lv = fetch(y - W2);
+#endif
+#if SBM_ABL != 1
     {
       int lvl = 2;
 #pragma unroll
@@ -350,6 +454,7 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
         lvl++;
       }
     }
+#endif
     int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
     u32 acc_lo = acc & 0xffffu, acc_hi = acc >> 16;
     bool mine = true;  // does this wavefront finalise this row?
@@ -370,6 +475,9 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
       }
     }
 
+#if SBM_ABL == 6
+    if (mine && produces) __builtin_amdgcn_raw_buffer_store_b16((short)(best ^ acc_lo ^ acc_hi ^ (u32)nn ^ (u32)pp), rs_d, ocol, orow, 0);
+#else
     if (mine) {
       int tsum = (int)Vt;
 #pragma unroll
@@ -392,24 +500,83 @@ __global__ void __launch_bounds__(64 * NWAVES) sad_fast_kernel(FastArgs a) {
           const int den = pp + nn - 2 * minsad + ad;
           int frac = 0;
           if (den != 0) {
+            // den = (p + n - 2 minsad) + |p - n| >= |p - n|, so the quotient is at most 256: one reciprocal estimate
+            // (relative error 2^-22) is within 1 of it and one exact remainder settles which way (24-bit products)
             const u32 num = (u32)ad << 8;
-            u32 qv = (u32)((float)num / (float)den);      // |p-n|*256 < 2^24: estimate is within 1 of the quotient
-            while ((u64)qv * (u32)den > num) qv--;
-            while ((u64)(qv + 1) * (u32)den <= num) qv++;
+            u32 qv = (u32)((float)num * __builtin_amdgcn_rcpf((float)den));
+            const int rem = (int)num - (int)__umul24(qv, (u32)den);
+            qv = rem < 0 ? qv - 1 : (rem >= den ? qv + 1 : qv);
             frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
           }
           out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
-          if (a.cost) a.cost[obase + (size_t)y * a.W] = (uint16_t)minsad;
+          if (a.cost) __builtin_amdgcn_raw_buffer_store_b16((short)minsad, rs_c, ocol, orow, 0);
         }
-        a.disp[obase + (size_t)y * a.W] = (int16_t)out;
+        __builtin_amdgcn_raw_buffer_store_b16((short)out, rs_d, ocol, orow, 0);
       }
     }
+#endif
 
     if (y + 1 < ye) {
       g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
+#if SBM_ABL != 5
       apply(lv, 1);
+#else
+#if SBM_FAST_PINGPONG
+#pragma unroll
+      for (int q = 0; q < NQ; q++) VA[q] = __builtin_bit_cast(uint2, VB[q]);
+#endif
+#endif
     }
   }
+}
+
+#if !SBM_FAST_PINGPONG
+hipError_t launch_sad_fast_pp(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
+                              int* xa, int* xb, hipStream_t s);
+
+// Device check behind the in-place accumulate: v_mqsad_pk_u16_u8 with vdst == src2 against the compiler's
+// non-aliased form, pseudo-random operands, single instructions and dependent chains (tools/ubench/mqsad_alias.hip
+// is the long version). One wavefront per SIMD-pair, a few microseconds, once per device and process.
+__global__ void __launch_bounds__(256) mqsad_inplace_selftest_kernel(unsigned* bad) {
+  unsigned long long st = (unsigned long long)(blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  unsigned nbad = 0;
+  for (int it = 0; it < 64; it++) {
+    unsigned long long accA[4], accR[4], win[4];
+    const unsigned pat = (unsigned)rnd() & ((it & 1) ? 0x00ffffffu : 0x000000ffu);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { accA[q] = accR[q] = rnd() & 0x3fff3fff3fff3fffull; win[q] = rnd(); }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        accR[q] = __builtin_amdgcn_mqsad_pk_u16_u8(win[(q + r) & 3], pat, accR[q]);
+        asm volatile("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(accA[q]) : "v"(win[(q + r) & 3]), "v"(pat));
+      }
+#pragma unroll
+    for (int q = 0; q < 4; q++) nbad += accA[q] != accR[q];
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+bool mqsad_inplace_ok(hipStream_t s) {
+  static int state[64];   // per device: 0 unknown, 1 ok, 2 not ok
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (state[dev] == 0) {
+    static const int env = [] { const char* e = getenv("SBM_FAST_INPLACE"); return e ? atoi(e) : 1; }();
+    unsigned* d = nullptr;
+    unsigned h = 1;
+    if (env && hipMalloc(&d, 4) == hipSuccess) {
+      if (hipMemsetAsync(d, 0, 4, s) == hipSuccess) {
+        hipLaunchKernelGGL(mqsad_inplace_selftest_kernel, dim3(64), dim3(256), 0, s, d);
+        if (hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) h = 1;
+      }
+      hipFree(d);
+    }
+    state[dev] = (env && h == 0) ? 1 : 2;
+  }
+  return state[dev] == 1;
 }
 
 bool sad_fast_supported(const Geom& g) {
@@ -423,6 +590,7 @@ bool sad_fast_supported(const Geom& g) {
   if (xhi - g.w2 + 1 <= g.w2) return false;
   return true;
 }
+#endif  // !SBM_FAST_PINGPONG
 
 template <int NDW, int NWAVES, int NTERM, int PW>
 static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
@@ -440,8 +608,10 @@ static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-// mode 0 (default): 64 disparities per wavefront, nd/64 cooperating wavefronts.  mode 1: one wavefront holds all
-// (<= 128) disparities -- kept for A/B measurements (env SBM_FAST_MODE=1).
+// mode 1 (default): 128 disparities per wavefront wherever nd > 64 -- one wavefront holds a pixel's whole disparity range
+// at nd <= 128 (no barriers, no merge, every per-row fixed cost paid once; 168 VGPRs = 3 wavefronts per SIMD with the
+// in-place accumulate), two cooperate up to nd 256.  mode 0 (SBM_FAST_MODE=0, and the ping-pong build): 64 disparities
+// per wavefront, nd/64 cooperating wavefronts -- the round-1/2 layout, kept for A/B measurements and as the fallback.
 template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, bool split, hipStream_t s) {
   if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, grid, s);
@@ -450,9 +620,10 @@ static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, bool split, 
   // per row; SBM_FAST_SPLIT=0 disables)
   if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW>(a, grid, s);
   if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, grid, s);
-  if constexpr (PW == 3) {
-    if (a.nd <= 128 && mode == 1) return launch_t<128, 1, NTERM, PW>(a, grid, s);
-  }
+  // (two cooperating 128-disparity wavefronts at nd 256 -- SBM_FAST_MODE=2 -- run the interior kernel 7 % faster but starve
+  // the border kernel until it has drained: 1080p step 3.13 -> 3.26 ms, profiles/r03_sad_isa_budget.md)
+  if (mode >= 1 && !split && a.nd <= 128) return launch_t<128, 1, NTERM, PW>(a, grid, s);
+  if (mode == 2 && !split && a.nd > 192) return launch_t<128, 2, NTERM, PW>(a, grid, s);
   if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, grid, s);
   if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, grid, s);
   return launch_t<64, 4, NTERM, PW>(a, grid, s);
@@ -462,7 +633,10 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
                            int* xa, int* xb, hipStream_t s) {
   *xa = *xb = 0;
   if (!sad_fast_supported(g)) return hipSuccess;
-  static const int mode = [] { const char* e = getenv("SBM_FAST_MODE"); return e ? atoi(e) : 0; }();
+#if !SBM_FAST_PINGPONG
+  if (!mqsad_inplace_ok(s)) return launch_sad_fast_pp(pf_l, pf_r, disp, cost, g, xa, xb, s);
+#endif
+  static const int mode = [] { const char* e = getenv("SBM_FAST_MODE"); return e ? atoi(e) : (SBM_FAST_PINGPONG ? 0 : 1); }();
   FastArgs a;
   a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? reinterpret_cast<uint16_t*>(cost) : nullptr;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;

@@ -10,6 +10,7 @@ src/slam/src/core/main.cpp:201-215 of the reference:
 with the status code and OpenCV's message, where cv::StereoBM::compute would throw cv::Error.
 """
 import ctypes
+import os
 import pathlib
 
 import numpy as np
@@ -99,7 +100,8 @@ class StereoBMError(RuntimeError):
 
 
 def library_path():
-    return _HERE / "lib" / "libsbm_hip.so"
+    # SBM_LIB_AB=<file name inside lib/>: A/B builds of the same HIP engine for kernel experiments (tools/exp); never a fallback
+    return _HERE / "lib" / os.environ.get("SBM_LIB_AB", "libsbm_hip.so")
 
 
 def load_library():
