@@ -445,6 +445,7 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
     const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
     fa = g.w2; fb = xhi - g.w2 + 1;   // the interior range launch_sad_fast covers; xend - fb == w/2 by construction
     g.cost16 = 1;
+    g.pfshift = sad_fast_pfshift(g);   // pre-scaled planes for the interior kernel's tagged winner search
   }
   h->last = g;
   // columns left and right of the fast range: clamped windows. They only matter if they can influence the output:
@@ -760,7 +761,7 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes) {
     const uint8_t* src = which == 0 ? h->pf_l : h->pf_r;
     HIPCHK(h, hipMemcpy2D(dst, g.W, src + g.padl, g.pitch, g.W, (size_t)g.n * g.H, hipMemcpyDeviceToHost));
     uint8_t* d = (uint8_t*)dst;
-    for (size_t i = 0; i < npix; i++) d[i] = (uint8_t)(d[i] - kPfBias);
+    for (size_t i = 0; i < npix; i++) d[i] = (uint8_t)((d[i] - kPfBias) >> g.pfshift);
     return SBM_OK;
   }
   if (which == 2) {

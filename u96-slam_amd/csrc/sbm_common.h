@@ -23,10 +23,15 @@ struct Geom {
   int col0, col1;      // valid-ROI columns [col0,col1)
   int want_cost;       // disp12_max_diff >= 0
   int cost16;          // the cost plane holds uint16 (fast + border kernels: sums <= 65534) instead of int32
+  int pfshift;         // the prefiltered planes hold (value << pfshift) + 1 (0 unless the fast path asks for it)
 };
 
 // Prefiltered planes store value+1 (range 1..2*cap+1 <= 127) so that 0 can act as the "masked byte" of
 // v_mqsad_pk_u16_u8; padding bytes are 0. sbm_debug_fetch() removes the bias again.
+// With Geom::pfshift = 2 the planes store 4*value+1 (<= 253): every absolute difference, hence every SAD, is a multiple
+// of 4, which leaves the two low bits of the packed 16-bit sums free for a register tag in the interior kernel's
+// winner search (sbm_sad_fast.hip; chosen by sad_fast_pfshift() when 4*maxS still fits 16 bits). The border kernels
+// take the scale out again when they stage a row.
 constexpr int kPfBias = 1;
 
 hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
@@ -44,6 +49,7 @@ hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t*
 // Fast path (interior columns, block size multiple of 3 up to 21, 16-bit sums). Returns hipErrorNotSupported
 // when the configuration is outside its envelope; *xa,*xb receive the column range it covered.
 bool sad_fast_supported(const Geom& g);
+int sad_fast_pfshift(const Geom& g);   // 2 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                            int* xa, int* xb, hipStream_t s);
 

@@ -26,6 +26,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 //   rtl (xsbl2.v:185-198):  lo = -32,  hi = 31,  off = 32;  rows 0 and H-1 are never written by the RTL (= 0)
 struct PfMap {
   int lo, hi, off, bias, rtl;
+  int shift;   // out = ((clip + off) << shift) + bias  (engine planes of the pre-scaled fast path, else 0)
 };
 __device__ __forceinline__ int clipmap(int v, const PfMap& m) { return (v < m.lo ? m.lo : (v > m.hi ? m.hi : v)) + m.off; }
 
@@ -41,10 +42,10 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t even_bytes(uint32_t w) { return w & 0x00ff00ffu; }
 __device__ __forceinline__ uint32_t odd_bytes(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c01u); }
 
-// packed (2 x i16): clip(a - b, lo, hi) + off
-__device__ __forceinline__ uint32_t diff_clip(uint32_t a, uint32_t b, s16x2 lo, s16x2 hi, s16x2 off) {
+// packed (2 x i16): (clip(a - b, lo, hi) + off) * mul + bias   (one v_pk_mad_i16 for scale and bias)
+__device__ __forceinline__ uint32_t diff_clip(uint32_t a, uint32_t b, s16x2 lo, s16x2 hi, s16x2 off, s16x2 mul, s16x2 bias) {
   s16x2 d = __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b);
-  d = __builtin_elementwise_min(__builtin_elementwise_max(d, lo), hi) + off;
+  d = (__builtin_elementwise_min(__builtin_elementwise_max(d, lo), hi) + off) * mul + bias;
   return __builtin_bit_cast(uint32_t, d);
 }
 
@@ -114,8 +115,9 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
       O[k][w] = odd_bytes(rw[k][w]);
     }
   const s16x2 vlo = {(short)m.lo, (short)m.lo}, vhi = {(short)m.hi, (short)m.hi};
-  const s16x2 voff = {(short)(m.off + m.bias), (short)(m.off + m.bias)};
-  const uint32_t edge = (uint32_t)(m.off + m.bias);
+  const s16x2 voff = {(short)m.off, (short)m.off};
+  const s16x2 vmul = {(short)(1 << m.shift), (short)(1 << m.shift)}, vbias = {(short)m.bias, (short)m.bias};
+  const uint32_t edge = (uint32_t)((m.off << m.shift) + m.bias);
 
 #pragma unroll
   for (int j = 0; j < PF_ROWS; j++) {
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
     if (y >= H) break;
     uint32_t out[4];
     if (m.rtl ? (y == 0 || y == H - 1) : ((H & 1) && y == H - 1)) {
-      out[0] = out[1] = out[2] = out[3] = (uint32_t)((m.rtl ? 0 : m.off) + m.bias) * 0x01010101u;
+      out[0] = out[1] = out[2] = out[3] = (uint32_t)(((m.rtl ? 0 : m.off) << m.shift) + m.bias) * 0x01010101u;
     } else {
       // vertical 1-2-1 sums (max 4*255: no carry between the halves), then the horizontal difference
       // s[i+2] - s[i] on packed pairs: pixels (4q, 4q+2) from the even sums, (4q+1, 4q+3) from the odd sums
@@ -135,8 +137,8 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const uint32_t pe = diff_clip(__builtin_amdgcn_alignbit(SE[q + 1], SE[q], 16), SE[q], vlo, vhi, voff);
-        const uint32_t po = diff_clip(__builtin_amdgcn_alignbit(SO[q + 1], SO[q], 16), SO[q], vlo, vhi, voff);
+        const uint32_t pe = diff_clip(__builtin_amdgcn_alignbit(SE[q + 1], SE[q], 16), SE[q], vlo, vhi, voff, vmul, vbias);
+        const uint32_t po = diff_clip(__builtin_amdgcn_alignbit(SO[q + 1], SO[q], 16), SO[q], vlo, vhi, voff, vmul, vbias);
         out[q] = pe | (po << 8);
       }
       // image columns 0 and W-1 carry the offset value
@@ -195,7 +197,7 @@ hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8
   const int rows = pf_rows((size_t)4 * g.n * g.W * g.H);
   const int ngroup = (g.H + rows - 1) / rows;
   dim3 grid((npiece * ngroup + 255) / 256, 2 * g.n);
-  const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0};
+  const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0, g.pfshift};
 #define SBM_PF(R) hipLaunchKernelGGL(prefilter_kernel<R>, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl, \
                      (size_t)g.W * g.H, (size_t)g.plane, (size_t)g.n * g.W * g.H, (size_t)g.n * g.W * g.H, m)
   if (rows == 2) SBM_PF(2); else if (rows == 8) SBM_PF(8); else SBM_PF(4);
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) pf_norm_vsum_kernel(const uint8_t* __rest
 __global__ void __launch_bounds__(256) pf_norm_resp_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                            const uint16_t* __restrict__ vs, uint8_t* __restrict__ pf_l,
                                                            uint8_t* __restrict__ pf_r, int W, int H, int pitch, int padl,
-                                                           int plane, int wsz2, int sg, int ss, int cap) {
+                                                           int plane, int wsz2, int sg, int ss, int cap, int pfshift) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
   const int img = blockIdx.z >> 1;
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(256) pf_norm_resp_kernel(const uint8_t* __rest
   const int val = (centre * sg - box * ss) >> 10;
   const int o = val < -cap ? 0 : (val > cap ? 2 * cap : val + cap);
   uint8_t* dst = ((blockIdx.z & 1) ? pf_r : pf_l) + (size_t)img * plane + (size_t)y * pitch + padl;
-  dst[x] = (uint8_t)(o + kPfBias);
+  dst[x] = (uint8_t)((o << pfshift) + kPfBias);
 }
 
 hipError_t launch_prefilter_norm(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r, uint16_t* vsum,
@@ -264,7 +266,7 @@ hipError_t launch_prefilter_norm(const uint8_t* d_left, const uint8_t* d_right, 
   hipLaunchKernelGGL(pf_norm_vsum_kernel, dim3(gx, (g.H + PFN_ROWS - 1) / PFN_ROWS, 2 * g.n), dim3(256), 0, s, d_left, d_right,
                      vsum, g.W, g.H, wsz2);
   hipLaunchKernelGGL(pf_norm_resp_kernel, dim3(gx, g.H, 2 * g.n), dim3(256), 0, s, d_left, d_right, vsum, pf_l, pf_r, g.W, g.H,
-                     g.pitch, g.padl, g.plane, wsz2, sg, ss, g.cap);
+                     g.pitch, g.padl, g.plane, wsz2, sg, ss, g.cap, g.pfshift);
   return hipGetLastError();
 }
 
@@ -276,7 +278,7 @@ hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, i
   const int ngroup = (H + rows - 1) / rows;
   // the kernel addresses images as (pair, side): image j = pair j/2, side j&1, so a dense array of images is a
   // sequence of pairs with a stride of two images; an odd last image goes in a second launch of one side
-  const PfMap m = rtl ? PfMap{-32, 31, 32, 0, 1} : PfMap{-cap, cap, cap, 0, 0};
+  const PfMap m = rtl ? PfMap{-32, 31, 32, 0, 1, 0} : PfMap{-cap, cap, cap, 0, 0, 0};
   const size_t img = (size_t)W * H;
   const unsigned gx = (unsigned)((npiece * ngroup + 255) / 256);
 #define SBM_PFD(R)                                                                                                          \

@@ -30,7 +30,10 @@ struct BorderArgs {
   int row0, row1, seg;
   int nsub, npacked;   // quad kernel: row segments walked in lockstep by one workgroup; workgroups that do so (full segments only)
   int xo[2];  // first output column (relative to lofs) of the left / right side; each side has w/2 columns
+  int pfshift; // the planes hold (value << pfshift) + 1 (pre-scaled for the interior kernel, sbm_common.h): every sum, capb and tex
+               // are scaled alike; only the uniqueness threshold and the stored cost go back to the unscaled sum
 };
+
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 typedef unsigned short bu16x2 __attribute__((ext_vector_type(2)));
@@ -169,7 +172,8 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
       for (int v = 0; v < WSZ; v++) tsum += Tcol[j + v];
       bool ok = tsum >= a.tex;
       if (a.uniq > 0) {
-        const int thresh = minsad + (minsad * a.uniq / 100);
+        const int ms = minsad >> a.pfshift;
+        const int thresh = (ms + (ms * a.uniq / 100)) << a.pfshift;
         bool hit = false;
         for (int dd = lane; dd < a.nd; dd += 64) hit |= (dd < mind - 1 || dd > mind + 1) && Sbuf[j][dd] <= thresh;
         ok = ok && __ballot(hit) == 0ull;
@@ -184,8 +188,8 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
           const int den = p + n - 2 * minsad + ad;
           out = ((a.nd - mind - 1 + a.mindisp) * 256 + (den != 0 ? (p - n) * 256 / den : 0) + 15) >> 4;
           if (a.cost) {
-            if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)minsad;
-            else static_cast<int32_t*>(a.cost)[o] = minsad;
+            if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)(minsad >> a.pfshift);
+            else static_cast<int32_t*>(a.cost)[o] = minsad >> a.pfshift;
           }
         }
         a.disp[o] = (int16_t)out;
@@ -436,8 +440,8 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       for (int j = 0; j < W2; j++) {
         // minsad * uniq / 100 with a 24-bit multiply and one mulhi (x / 100 == mulhi(x, 0x51EB851F) >> 5 for 32-bit x); the
         // plain expression costs two quarter-rate 32-bit multiplies per output column. The envelope keeps the product < 2^23.
-        const unsigned minsad = bestk[j] >> 16;
-        const unsigned thresh = minsad + (__umulhi(__umul24(minsad, (unsigned)a.uniq), 0x51EB851Fu) >> 5);
+        const unsigned minsad = (bestk[j] >> 16) >> a.pfshift;          // the threshold is defined on the unscaled sum
+        const unsigned thresh = (minsad + (__umulhi(__umul24(minsad, (unsigned)a.uniq), 0x51EB851Fu) >> 5)) << a.pfshift;
         const unsigned Tq = min(thresh + 1u, 65535u);                  // sums are <= 65534: sv <= thresh <=> Tq - sv > 0
         const unsigned T2 = Tq | (Tq << 16);
         const unsigned c2 = bpk_min(bpk_sub_sat(T2, (unsigned)S[j]), 0x00010001u) +
@@ -481,7 +485,8 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       const int n = mind - 1 >= 0 ? sb[mind - 1] : sb[1];
       bool ok = ts >= a.tex;
       if (a.uniq > 0) {
-        const int tl = min(minsad + (minsad * a.uniq / 100), 65534);
+        const int ms = minsad >> a.pfshift;
+        const int tl = min((ms + (ms * a.uniq / 100)) << a.pfshift, 65534);
         const int expected = 1 + (mind + 1 < a.nd && p <= tl) + (mind - 1 >= 0 && n <= tl);   // of mind-1, mind, mind+1
         ok = ok && Hit[tid] == expected;
       }
@@ -500,8 +505,8 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
         }
         out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
         if (a.cost) {
-          if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)minsad;
-          else static_cast<int32_t*>(a.cost)[o] = minsad;
+          if (a.cost16) static_cast<uint16_t*>(a.cost)[o] = (uint16_t)(minsad >> a.pfshift);
+          else static_cast<int32_t*>(a.cost)[o] = minsad >> a.pfshift;
         }
       }
       a.disp[o] = (int16_t)out;
@@ -519,10 +524,11 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
   BorderArgs a;
   a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? cost : nullptr; a.cost16 = g.cost16;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
-  a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex; a.uniq = g.uniq;
-  a.filtered = g.filtered; a.capb = g.cap + kPfBias;
+  a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex << g.pfshift; a.uniq = g.uniq;
+  a.filtered = g.filtered; a.capb = (g.cap << g.pfshift) + kPfBias;
   a.row0 = g.row0; a.row1 = g.row1;
   a.xo[0] = 0; a.xo[1] = xb;
+  a.pfshift = g.pfshift;
   const int rows = g.row1 - g.row0;
   // short segments: each row costs a latency-bound staging round trip, so favour many concurrent workgroups
   static const int seg_rows_env = [] { const char* e = getenv("SBM_BORDER_SEG"); return e ? atoi(e) : 0; }();

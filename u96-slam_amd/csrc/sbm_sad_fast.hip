@@ -65,6 +65,7 @@ struct FastArgs {
   int strips, nseg, npairs;  // grid decomposition (1-D grid of strips*nseg*npairs workgroups)
   int uniq_plain;            // 8 * (maxS * uniq / 100 + 1) fits 16 bits: deficit partial sums need no saturating adds
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
+  int pfshift;               // the planes hold (value << pfshift) + 1: every sum below is scaled by 1 << pfshift (0 or 2)
 };
 
 __device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t* p) {
@@ -84,6 +85,10 @@ __device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b) {
 }
 __device__ __forceinline__ u32 pk_add_sat(u32 a, u32 b) {
   u16x2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+  return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) {
+  u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
   return __builtin_bit_cast(u32, r);
 }
 // one v_min3_u32 (the compiler re-associates min(a, min(b, c)) chains and then only finds about half of them)
@@ -359,6 +364,26 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
       best = ((f & 0x3fffu) << 16) | ((f >> 16) & 63u);
     }
 #else
+    if (NR >= 16 && a.pfshift == 2) {
+      // Pre-scaled planes (sbm_common.h): every sum is a multiple of 4, so the two low bits of each packed half can carry
+      // a register tag. Registers j, j + NR/4, j + NR/2, j + 3NR/4 (tags 0..3 = the top two bits of the buffer index) are
+      // reduced with packed 16-bit minima first -- one OR (a full-rate instruction) and one v_pk_min_u16 per register
+      // instead of two key builds and a v_min3_u32 -- and only the NR/4 survivors get 32-bit keys. Ties: the smaller
+      // (sum, tag, low index bits) triple is the smaller buffer index, as in the plain key scan.
+      constexpr int NG = NR / 4;
+      u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+      for (int j = 0; j < NG; j++) {
+        const u32 g01 = pk_min(S[j], S[j + NG] | 0x00010001u);
+        const u32 g23 = pk_min(S[j + 2 * NG] | 0x00020002u, S[j + 3 * NG] | 0x00030003u);
+        const u32 gm = pk_min(g01, g23);
+        const u32 klo = (gm << 16) | (u32)(2 * j);
+        const u32 khi = (gm & 0xffff0000u) | (u32)(2 * j + 1);
+        b[j & 3] = umin3(b[j & 3], klo, khi);
+      }
+      const u32 bt = min(min(b[0], b[1]), min(b[2], b[3]));       // (4 S + tag) << 16 | low index bits
+      best = (bt & 0xfffc0000u) | (((bt >> 16) & 3u) * (u32)(2 * NG) + (bt & 0xffffu));
+    } else {
 #pragma unroll
     for (int g0 = 0; g0 < NR; g0 += 32) {
       u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -370,6 +395,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
       }
       const u32 bg = min(min(b[0], b[1]), min(b[2], b[3])) + (u32)(2 * g0);
       best = min(best, bg);
+    }
     }
 #endif
     best += (u32)d0;
@@ -385,8 +411,9 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     // ---- uniqueness (part 1): saturating sum of the deficits max(T - S[d], 0), per 16-bit half --------------
     u32 acc = 0, T = 0;
     if (a.uniq > 0) {
-      const int thresh = minsad + (minsad * a.uniq / 100);
-      T = (u32)min(thresh + 1, 65535);
+      const int ms = minsad >> a.pfshift;                     // the threshold is defined on the unscaled sum
+      const int thresh = ms + (ms * a.uniq / 100);
+      T = (u32)min((thresh + 1) << a.pfshift, 65535);
       const u32 T2 = T | (T << 16);
       // independent accumulators of 8 registers each (a single chain is one dependent v_pk_sub -> v_pk_add pair per
       // register with a wait state in between). Every deficit is at most T - minsad <= maxS*uniq/100 + 1; when 8 of them
@@ -509,7 +536,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
             frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
           }
           out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
-          if (a.cost) __builtin_amdgcn_raw_buffer_store_b16((short)minsad, rs_c, ocol, orow, 0);
+          if (a.cost) __builtin_amdgcn_raw_buffer_store_b16((short)(minsad >> a.pfshift), rs_c, ocol, orow, 0);
         }
         __builtin_amdgcn_raw_buffer_store_b16((short)out, rs_d, ocol, orow, 0);
       }
@@ -579,6 +606,19 @@ bool mqsad_inplace_ok(hipStream_t s) {
   return state[dev] == 1;
 }
 
+// Pre-scaled planes for the tagged winner search: 4 * value + 1 must fit a byte and 4 * maxS + 3 a packed half; the
+// uniqueness envelope is the one of sad_fast_supported() on the scaled sums. SBM_FAST_PFSHIFT=0 turns it off.
+int sad_fast_pfshift(const Geom& g) {
+  static const int env = [] { const char* e = getenv("SBM_FAST_PFSHIFT"); return e ? atoi(e) : 2; }();
+  if (env != 2 || !sad_fast_supported(g)) return 0;
+  const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
+  if (4 * 2 * g.cap + 1 > 255) return 0;
+  if (4 * maxs + 3 > 65535) return 0;
+  if (2 * (4 * (maxs * g.uniq / 100 + 1)) >= 65535) return 0;
+  if ((long)g.tex * 4 > 0x3fffffff) return 0;
+  return 2;
+}
+
 bool sad_fast_supported(const Geom& g) {
   if (g.wsz < 5 || g.wsz > 27) return false;   // every odd window 5..27: multiples of 3 with 3-column sums, the rest 1-column
   if (g.nd > 256) return false;
@@ -640,8 +680,8 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   FastArgs a;
   a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? reinterpret_cast<uint16_t*>(cost) : nullptr;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
-  a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex; a.uniq = g.uniq;
-  a.filtered = g.filtered; a.capb = g.cap + kPfBias;
+  a.nd = g.nd; a.mindisp = g.mindisp; a.lofs = g.lofs; a.rofs = g.rofs; a.tex = g.tex << g.pfshift; a.uniq = g.uniq;
+  a.filtered = g.filtered; a.capb = (g.cap << g.pfshift) + kPfBias; a.pfshift = g.pfshift;
   a.row0 = g.row0; a.row1 = g.row1;
   const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);
   a.xc0 = g.w2; a.xc1 = xhi - g.w2 + 1;
@@ -686,7 +726,7 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   {
     const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
     static const int plain_env = [] { const char* e = getenv("SBM_FAST_UNIQ_PLAIN"); return e ? atoi(e) : 1; }();
-    a.uniq_plain = plain_env && 8 * (maxs * g.uniq / 100 + 1) <= 65535;   // (NR / 4 <= 8 registers per accumulator)
+    a.uniq_plain = plain_env && 8 * ((maxs * g.uniq / 100 + 1) << g.pfshift) <= 65535;   // (8 registers per accumulator)
   }
   dim3 grid((unsigned)strips * nseg * g.n);
   static const int split_env = [] { const char* e = getenv("SBM_FAST_SPLIT"); return e ? atoi(e) : 1; }();
