@@ -123,6 +123,9 @@ def main():
                     help="N>1: the whole global batch starts on rank 0; every step scatters it in chunks of --chunk pairs, "
                          "computes and gathers the maps back (double-buffered point-to-point over RCCL), all inside the timed region")
     ap.add_argument("--chunk", type=int, default=8, help="pairs per transfer chunk of --scatter")
+    ap.add_argument("--feed", choices=("resident", "host"), default="resident",
+                    help="host: every rank streams its own shard from PINNED host memory through the engine's chunked three-stream "
+                         "host entry point (sbm_compute_batch), inputs and maps crossing PCIe inside the timed region")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -198,6 +201,7 @@ def main():
     def sync_all():
         torch.cuda.synchronize(dev)
         bm.synchronize()
+        feed_out[0] = 0
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -209,7 +213,35 @@ def main():
             return bm.compute_device(l, r, sync=True)
         return bm.compute_device(l.to(dev), r.to(dev), sync=True).cpu()
 
+    host_feed = args.feed == "host" and not scatter
+    hL = hR = hD = None
+    if host_feed:
+        # this rank's shard in pinned host memory (hipHostMalloc through torch): what a per-rank feeder thread would own
+        hL, hR = torch.from_numpy(Lh).pin_memory(), torch.from_numpy(Rh).pin_memory()
+        hD = torch.empty((B, H, W), dtype=torch.int16).pin_memory()
+        hLn, hRn, hDn = hL.numpy(), hR.numpy(), hD.numpy()
+        # second buffer set of the double-buffered feeder (batch k+1 is filled / submitted while batch k is in flight)
+        feed_keep = [(hL.clone().pin_memory(), hR.clone().pin_memory(), torch.empty((B, H, W), dtype=torch.int16).pin_memory()) for _ in range(2)]
+        feed_sets = [(hLn, hRn, hDn)] + [(a.numpy(), b.numpy(), c.numpy()) for a, b, c in feed_keep]
+    feed_i, feed_out = [0], [0]   # submissions made / not yet waited for (sbm_synchronize drains the queue)
+    feed_async = os.environ.get("SBM_BENCH_FEED", "async") == "async"   # SBM_BENCH_FEED=sync: one sbm_compute_batch call per step
+
     def step():
+        if host_feed:
+            if feed_async:
+                # asynchronous dense feed (sbm_submit_dense / sbm_wait_oldest): batch k+1 crosses PCIe while batch k computes
+                # and batch k-1's maps return; the region's closing sbm_synchronize() waits for the last submissions
+                bm.submit_host(*feed_sets[feed_i[0] % 3])
+                feed_i[0] += 1
+                feed_out[0] += 1
+                if feed_out[0] >= 3:         # three batches in flight: one arriving, one computing, one leaving
+                    bm.wait_host()
+                    feed_out[0] -= 1
+                return
+            # one synchronous call of the host entry point (sbm_compute_batch): inside the call chunks of pairs flow through an
+            # H2D stream, the compute stream and a D2H stream; it returns when the maps are in the caller's (pinned) memory
+            bm.compute(hLn, hRn, hDn)
+            return
         if scatter:
             from u96_slam_amd import shard
 
@@ -223,7 +255,7 @@ def main():
 
     # stage events recorded on the engine's stream inside the timed region, no host sync; every 4th step is instrumented (six
     # event records cost ~25 us per step: sampling keeps the timed rate within ~0.5 % of the un-instrumented one)
-    bm.set_profiling(0 if args.no_profile else (3 if args.steps >= 8 else 2))
+    bm.set_profiling(0 if (args.no_profile or host_feed) else (3 if args.steps >= 8 else 2))
     sync_all()
     t0 = time.perf_counter()
     gathered = None
@@ -236,6 +268,7 @@ def main():
             src = dD if backend == "nccl" else dD.cpu()
             gathered = shard.gather_disparities(src, world * B, dst=0)
     bm.synchronize()
+    feed_out[0] = 0
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -248,6 +281,125 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    kernel_name = bm.last_kernel()
+
+    # ---- per-step distribution (SURVEY.md 8d "report median and min"): a further pass of min(steps, 50) steps with one HIP event
+    # per step on the ENGINE's stream (torch.cuda.Event only sees torch's streams unless it is recorded on this external one);
+    # outside the timed region, so `value` is not perturbed
+    step_ms = []
+    if not scatter:
+        nper = max(2, min(args.steps, 50))
+        if host_feed:
+            bm.synchronize()
+            feed_out[0] = 0
+            for _ in range(nper):           # host time between consecutive completions (the queue stays three deep)
+                t1 = time.perf_counter()
+                step()
+                step_ms.append((time.perf_counter() - t1) * 1e3)
+            bm.synchronize()
+            feed_out[0] = 0
+            step_ms = step_ms[3:] if len(step_ms) > 6 else step_ms   # (the first submissions only fill the queue)
+        else:
+            es = torch.cuda.ExternalStream(bm.stream(), device=dev)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(nper + 1)]
+            evs[0].record(es)
+            for i in range(nper):
+                step()
+                evs[i + 1].record(es)
+            bm.synchronize()
+            torch.cuda.synchronize(dev)
+            step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(nper)]
+    step_ms.sort()
+
+    # ---- multi-GPU evidence in the default line (no flag needed): rank identity over the real backend, and min(steps, 10)
+    # steps of the chunked double-buffered point-to-point scatter/gather from rank 0 (the path north_star names)
+    rccl = sg = None
+    if dist is not None:
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+        idents = [None] * world
+        dist.all_gather_object(idents, (rank, local_rank, ident))
+        rccl = {"backend": backend, "ranks_seen": len(idents), "distinct_devices": len({i[2] for i in idents}),
+                "devices": [i[2] for i in idents]}
+        if not scatter and not host_feed:
+            from u96_slam_amd import shard
+
+            nsg = max(1, min(args.steps, 10))
+            if rank == 0:
+                parts = [synth.make_batch(r * B, uniq, W, H, nd) for r in range(world)]
+                gL = torch.from_numpy(np.concatenate([np.concatenate([pp[0]] * reps)[:B] for pp in parts])).to(xdev)
+                gR = torch.from_numpy(np.concatenate([np.concatenate([pp[1]] * reps)[:B] for pp in parts])).to(xdev)
+                gD = torch.empty((world * B, H, W), dtype=torch.int16, device=xdev)
+
+            def sg_step():
+                shard.compute_sharded_chunked(compute_chunk, gL, gR, world * B, (H, W), chunk=args.chunk, src=0, device=xdev, out=gD)
+
+            sg_step()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(nsg):
+                sg_step()
+            sync_all()
+            tsg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tsg, op=dist.ReduceOp.MAX)
+            sg_ms = float(tsg.item()) / nsg * 1e3
+            # the same chunks computed back to back without any transfer: what the scatter/gather adds is sg_ms - that
+            t1 = time.perf_counter()
+            for _ in range(nsg):
+                for c0 in range(0, B, args.chunk):
+                    bm.compute_device(dL[c0:c0 + args.chunk], dR[c0:c0 + args.chunk], sync=True)
+            tcc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tcc, op=dist.ReduceOp.MAX)
+            chunk_ms = float(tcc.item()) / nsg * 1e3
+            in_bytes, out_bytes = 2.0 * (world - 1) * B * W * H, 2.0 * (world - 1) * B * W * H
+            sg = {"ms_per_step": round(sg_ms, 4), "value": round(world * B * W * H * nd / (sg_ms * 1e-3) / 1e6, 2),
+                  "unit": "Mpix-disparities/s", "steps": nsg, "chunk": args.chunk, "backend": "RCCL" if backend == "nccl" else backend,
+                  "compute_only_ms_per_step": round(chunk_ms, 4),
+                  "root_link_GBps": round((in_bytes + out_bytes) / (sg_ms * 1e-3) / 1e9, 2),
+                  "overlap_frac": round(max(0.0, min(1.0, chunk_ms / sg_ms)), 4) if sg_ms > 0 else None,
+                  "note": "global batch resident on rank 0, chunked double-buffered point-to-point scatter of the pairs + gather of the "
+                          "maps inside the timed region; overlap_frac = per-rank chunked compute time / scatter-gather step time "
+                          "(1.0 = the transfers are completely hidden under the computation)"}
+
+    # ---- host feed: the three legs on their own (resident compute, H2D of the inputs, D2H of the maps) -> how much of the
+    # shorter legs the three-stream pipeline hides: overlap_frac = 1 when a step costs only its slowest leg, 0 when the sum
+    feed_legs = None
+    if host_feed:
+        nleg = max(2, min(args.steps, 20))
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(nleg):
+            dL.copy_(hL, non_blocking=True)
+            dR.copy_(hR, non_blocking=True)
+        e1.record()
+        for _ in range(nleg):
+            hD.copy_(dD, non_blocking=True)
+        e2.record()
+        torch.cuda.synchronize(dev)
+        h2d_ms, d2h_ms = e0.elapsed_time(e1) / nleg, e1.elapsed_time(e2) / nleg
+        bm.launch_raw(B, pl, pr, W, H, pd)     # (re-sizes the engine's scratch from chunk to batch size: not timed)
+        bm.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nleg):
+            bm.launch_raw(B, pl, pr, W, H, pd)
+        bm.synchronize()
+        res_ms = (time.perf_counter() - t1) / nleg * 1e3
+        # the synchronous entry point on the same data: one sbm_compute_batch call per step (chunked three-stream pipeline
+        # INSIDE the call; nothing of the next call can start before this one has returned)
+        nq = max(3, min(args.steps, 20))
+        bm.compute(hLn, hRn, hDn)
+        t1 = time.perf_counter()
+        for i in range(nq):
+            bm.compute(hLn, hRn, hDn)
+        queue_ms = (time.perf_counter() - t1) / nq * 1e3
+        feed_ms = elapsed / args.steps * 1e3
+        legs = (res_ms, h2d_ms, d2h_ms)
+        feed_legs = {"resident_compute_ms": round(res_ms, 4), "h2d_ms": round(h2d_ms, 4), "d2h_ms": round(d2h_ms, 4),
+                     "h2d_alone_GBps": round(2.0 * B * W * H / (h2d_ms * 1e-3) / 1e9, 2), "d2h_alone_GBps": round(2.0 * B * W * H / (d2h_ms * 1e-3) / 1e9, 2),
+                     "overlap_frac": round(max(0.0, min(1.0, 1.0 - (feed_ms - max(legs)) / max(sum(legs) - max(legs), 1e-9))), 4),
+                     "sync_call_ms_per_step": round(queue_ms, 4)}
+
     total_pairs = world * B * args.steps
     pixdisp_per_pair = W * H * nd
     value = total_pairs * pixdisp_per_pair / elapsed / 1e6
@@ -255,8 +407,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel ---------------------------------------------------------------------
-        stage = "sad" if prof["sad"] > prof["border"] else "border"
-        kms = prof[stage]
+        kms = prof["sad"]   # the SAD/WTA kernel of the call (interior kernel, or the generic one: `kernel` says which)
         algo_bytes = 4.0 * W * H * B  # read L+R (2 B/px) + write int16 disparity (2 B/px) per pair
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         traffic = None
@@ -266,7 +417,11 @@ def main():
             try:
                 tj = json.loads(tfile.read_text())
                 key = f"{args.workload}_w{wsz}_b{B}"
-                if key in tj:
+                if key in tj and tj[key].get("kernel") and tj[key]["kernel"] != kernel_name:
+                    # the committed counters were taken on another kernel instantiation: never attach them to this one
+                    pmc_extra = {"traffic_reason": f"profiles/hbm_traffic.json[{key}] was measured on '{tj[key]['kernel']}', this run launched "
+                                                   f"'{kernel_name}': re-run tools/profile_round.sh"}
+                elif key in tj:
                     traffic = tj[key].get("bytes_per_launch")
                     # what actually bounds the kernel: VALU issue, from the same committed PMC run
                     pmc_extra = {k: tj[key][k] for k in ("valu_busy_frac", "lds_busy_frac", "lane_ops_per_pixel_disparity") if k in tj[key]}
@@ -275,8 +430,7 @@ def main():
                 traffic = None
         # `bound` follows the bench contract ("hbm" | "mfma"): the HBM figure is what north_star asks for; the kernel itself
         # is limited by VALU issue (`limiter`, `valu_busy_frac`), so `frac` is informational, not a measure of its quality
-        fast_path = prof["sad"] > 0 and prof["border"] < prof["sad"]
-        roofline = {"bound": "hbm", "limiter": "valu", "kernel": "sad_fast_kernel" if fast_path else "sad_generic_kernel (fast path off)",
+        roofline = {"bound": "hbm", "limiter": "valu", "kernel": kernel_name,
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
@@ -377,11 +531,32 @@ def main():
                        + ("texture 10 / uniqueness 10 / disp12MaxDiff 1 / speckle 50,32" if post else "texture 10 / uniqueness 10, no LR/speckle"),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, " + (
                            f"global batch on rank 0: chunked ({args.chunk} pairs) double-buffered point-to-point scatter + gather over {'RCCL' if backend == 'nccl' else backend} inside the timed region" if scatter
-                           else "disparity maps gathered on rank 0 each step" if (args.gather and world > 1) else "shards resident, no data-path collective")},
+                           else "disparity maps gathered on rank 0 each step" if (args.gather and world > 1)
+                           else "every rank streams its shard from pinned host memory (PCIe inside the timed region)" if host_feed
+                           else "shards resident, no data-path collective (value); scatter_gather = the chunked RCCL scatter/gather from rank 0")},
+            "ms_per_step_median": round(step_ms[len(step_ms) // 2], 4) if step_ms else None,
+            "ms_per_step_min": round(step_ms[0], 4) if step_ms else None,
             "ms_per_pair": round(elapsed / (B * args.steps) * 1e3, 5),
             "pairs_per_s": round(total_pairs / elapsed, 1),
             "roofline": roofline, "roofline_prefilter": roofline_pf, "cpu_baseline": cpu,
         }
+        if step_ms:
+            out["ms_per_step_from"] = (f"{len(step_ms)} further steps, " + ("host wall clock per sbm_compute_batch call" if host_feed else "one HIP event per step on the engine's stream"))
+        if rccl is not None:
+            out["rccl"] = rccl
+        if sg is not None:
+            out["scatter_gather"] = sg
+        if host_feed:
+            nbytes_in, nbytes_out = 2.0 * B * W * H, 2.0 * B * W * H
+            out["host_feed"] = {"memory": "pinned (torch pin_memory = hipHostMalloc)", "h2d_GBps": round(nbytes_in / (ms_per_step * 1e-3) / 1e9, 2),
+                                "d2h_GBps": round(nbytes_out / (ms_per_step * 1e-3) / 1e9, 2),
+                                "bytes_per_step_each_way": nbytes_in, **(feed_legs or {}),
+                                "api": "sbm_submit_dense / sbm_wait_oldest" if feed_async else "sbm_compute_batch",
+                                "note": "every rank feeds its own shard from pinned host memory through the asynchronous dense feed (whole batches, "
+                                        "three in flight: H2D stream | compute stream | D2H stream); rates are bytes per direction over the whole "
+                                        "step; overlap_frac = 1 when a step costs only its slowest leg (measured alone: resident_compute_ms, h2d_ms, "
+                                        "d2h_ms), 0 when it costs their sum; sync_call_ms_per_step = the same batch through one synchronous "
+                                        "sbm_compute_batch call per step (chunked pipeline inside the call)"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

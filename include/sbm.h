@@ -122,6 +122,17 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
                        void* d_disp, int sync);
 
 /* Block until everything queued on the handle's stream has finished. */
+/* Asynchronous dense feed (what a per-GPU feeder thread of a multi-GPU job uses; bench.py --feed host): sbm_submit_dense
+ * queues one dense batch -- left/right: n*height*width bytes each, disp: n*height*width int16, all in HOST memory that
+ * should be pinned -- and returns at once; at most three submissions are in flight (a fourth call first waits for the oldest).
+ * Inputs cross PCIe on an H2D stream, the kernels run on the handle's stream, the maps return on a D2H stream, so batch k+1
+ * arrives while batch k computes and batch k-1 leaves (two device staging sets, re-used through stream dependencies). sbm_wait_oldest blocks until the oldest outstanding submission's maps
+ * are in `disp` (returns SBM_OK at once when nothing is outstanding). The buffers of a submission must stay untouched until
+ * it has been waited for. The reference's call is synchronous (main.cpp:215); this pair exists because a feeder that keeps
+ * the GPU busy across calls needs it. */
+int sbm_submit_dense(sbm_handle* h, int n, const uint8_t* left, const uint8_t* right, int width, int height, int16_t* disp);
+int sbm_wait_oldest(sbm_handle* h);
+
 int sbm_synchronize(sbm_handle* h);
 
 /* Intermediate planes of the LAST sbm_compute_device call, for stage-by-stage parity tests.
@@ -136,11 +147,17 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
  *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
  * enabled = 3: as 2, but only every 4th call is instrumented (the six event records cost ~25 us per call at the bench size;
  *              sampling keeps a timed region close to the un-instrumented rate).
- * names: "prefilter", "sad" (fast SAD/WTA kernel; every SAD launch of the call when it is pipelined), "border" (what
- * is left of the border-column kernel after the interior kernel has finished; the generic kernel when the fast path
- * is off), "lrcheck", "speckle", "total". */
+ * names: "prefilter", "sad" (the SAD/WTA kernel of the call: the interior kernel, or the generic kernel when the fast path is
+ * off -- sbm_last_kernel_name() says which), "border" (what is left of the border-column kernel after the interior kernel
+ * has finished; ~0 when the fast path is off), "lrcheck", "speckle", "total". */
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
+
+/* Which SAD kernel the LAST sbm_compute_device call launched, as text: the template instantiation of the interior
+ * kernel ("sad_fast_kernel<128,1,5,3,true> pfshift=2"; "sad_fast_pp_kernel<...>" = its two-accumulator fallback build)
+ * or "sad_generic_kernel" when the configuration is outside the fast envelope. bench.py compares it with the kernel the
+ * committed counter profile was taken on, so that stale counters are never attached to a different kernel. */
+int sbm_last_kernel_name(sbm_handle* h, char* dst, size_t dst_bytes);
 
 /* ---- consumers of the disparity map --------------------------------------------
  * Device-side versions of what the reference does with the map right after compute(), so that only the small

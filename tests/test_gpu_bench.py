@@ -30,10 +30,65 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["bit_exact_vs_gpu"] is True
     assert cb["opencv"].startswith(("cv2 ", "unavailable"))      # the probe outcome is always recorded
+    # the launched SAD kernel is named (template tuple) and the per-step distribution is reported
+    assert j["roofline"]["kernel"].startswith("sad_fast_kernel<128,1,5,3,true>")
+    assert 0 < j["ms_per_step_min"] <= j["ms_per_step_median"]
+    # counters from the committed profile are only attached to the kernel they were measured on
+    assert (j["roofline"]["traffic"] is not None) != ("traffic_reason" in j["roofline"]) or j["roofline"]["traffic"] is None
+
+
+def test_host_feed_line():
+    j = _run(["--steps", "4", "--warmup", "1", "--pairs", "32", "--no-cpu-baseline", "--feed", "host"])
+    hf = j["host_feed"]
+    assert "pinned host memory" in j["config"]["parallelism"] and hf["h2d_GBps"] > 0 and hf["d2h_GBps"] > 0
+    assert 0.0 <= hf["overlap_frac"] <= 1.0 and hf["resident_compute_ms"] > 0
 
 
 @pytest.mark.parametrize("extra", [[], ["--scatter", "--chunk", "3"]])
 def test_two_ranks_self_launched(extra):
     j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "8"] + extra, env={"SBM_BENCH_BACKEND": "gloo"})
     assert j["n_gpus"] == 2 and j["config"]["global_pairs_per_step"] == 16 and j["value"] > 0
-    assert ("chunked" in j["config"]["parallelism"]) == bool(extra)
+    assert ("chunked (" in j["config"]["parallelism"]) == bool(extra)
+    # the default line carries the multi-GPU evidence without any flag: rank identity + the chunked scatter/gather
+    assert j["rccl"]["ranks_seen"] == 2 and j["rccl"]["distinct_devices"] >= 1
+    if not extra:
+        sg = j["scatter_gather"]
+        assert sg["ms_per_step"] > 0 and sg["value"] > 0 and sg["chunk"] == 8 and sg["backend"] == "gloo" and 0 <= sg["overlap_frac"] <= 1
+        assert j["ms_per_step_median"] >= j["ms_per_step_min"] > 0
+
+
+def test_async_dense_feed_matches_the_synchronous_call():
+    """sbm_submit_dense / sbm_wait_oldest: three batches in flight on two device staging sets, results identical to
+    sbm_compute_batch and to the oracle, buffers of different submissions never mix."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "oracle"))
+    import _pkg
+    import sbm_oracle
+
+    pkg = _pkg.load()
+    from u96_slam_amd import synth
+
+    W, H, nd, B = 200, 64, 32, 5
+    bm = pkg.StereoBM.create(nd, 9, device=0)
+    bm.setUniquenessRatio(10); bm.setDisp12MaxDiff(1); bm.setSpeckleWindowSize(30); bm.setSpeckleRange(16)
+    p = sbm_oracle.make_params(nd, 9, 31, 0, 10, 10, 30, 16, 1)
+    batches = []
+    for k in range(7):     # more submissions than queue slots
+        L, R = synth.make_batch(100 * k, B, W, H, nd)
+        hl, hr = torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()
+        hd = torch.full((B, H, W), 12345, dtype=torch.int16).pin_memory()
+        batches.append((L, R, hl, hr, hd))
+    for k, (L, R, hl, hr, hd) in enumerate(batches):
+        bm.submit_host(hl.numpy(), hr.numpy(), hd.numpy())
+        if k >= 2:
+            bm.wait_host()
+            done = batches[k - 2]
+            assert np.array_equal(done[4].numpy(), sbm_oracle.compute_batch(p, done[0], done[1]))
+    bm.synchronize()         # drains the last two
+    for L, R, hl, hr, hd in batches:
+        ref = sbm_oracle.compute_batch(p, L, R)
+        assert np.array_equal(hd.numpy(), ref)
+        assert np.array_equal(bm.compute(L, R), ref)
+    bm.wait_host()           # nothing outstanding: returns at once

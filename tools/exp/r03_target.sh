@@ -1,7 +1,7 @@
 #!/bin/bash
-# sweep of the interior kernel's workgroup target (row segmentation) after the move to 5 wavefronts per SIMD
-for wl in kitti ref640 fhd; do
-  for t in 2800 3600 4400 5000 5600 6400 7200 8400 10000 12800; do
+# sweep of the interior kernel's workgroup target (row segmentation) for the single-wavefront 128-disparity kernel
+for wl in ${WLS:-kitti}; do
+  for t in ${TARGETS:-3000 4200 5600 6200 7200 8400 9300 10500 12400 15000}; do
     SBM_FAST_TARGET=$t python3 bench.py --no-cpu-baseline --workload $wl --steps 40 --warmup 5 2>/dev/null | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read()); s=j['roofline']['stage_ms']

@@ -15,6 +15,7 @@
 #include "sbm_common.h"
 
 using namespace sbm;
+namespace sbm { thread_local char g_sad_kernel_name[96] = ""; }
 
 struct sbm_handle {
   sbm_params p;
@@ -46,9 +47,20 @@ struct sbm_handle {
   size_t pin_bytes;
   // copy streams + per-chunk events of the pipelined host batch path (created on first use)
   hipStream_t stream_in, stream_out;
+  // asynchronous dense feed (sbm_submit_dense / sbm_wait_oldest): two device staging sets, up to three submissions in
+  // flight (one arriving, one computing, one leaving); events are indexed by submission number & 3
+  uint8_t *fq_l[2], *fq_r[2];
+  int16_t* fq_d[2];
+  int fq_n, fq_W, fq_H;
+  hipEvent_t ev_fq_in[4], ev_fq_done[4], ev_fq_out[4];
+  bool fq_ok;
+  unsigned fq_submitted, fq_waited;
+  int16_t* fq_pending_dst;     // maps of the newest submission not yet queued for their trip home (see sbm_submit_dense)
+  size_t fq_pending_bytes;
   static constexpr int kChunks = 64;
   hipEvent_t ev_in[kChunks], ev_done[kChunks];
   bool pipe_ok;
+  char last_kernel[96];   // SAD kernel of the last sbm_compute_device call (sbm_last_kernel_name)
   // last launch (for sbm_debug_fetch)
   Geom last;
   bool have_last;
@@ -159,6 +171,8 @@ static void free_fpga(sbm_handle* h) {
 
 static void free_staging(sbm_handle* h) {
   hipFree(h->st_l); hipFree(h->st_r); hipFree(h->st_d);
+  for (int k = 0; k < 2; k++) { hipFree(h->fq_l[k]); hipFree(h->fq_r[k]); hipFree(h->fq_d[k]); h->fq_l[k] = h->fq_r[k] = nullptr; h->fq_d[k] = nullptr; }
+  h->fq_n = h->fq_W = h->fq_H = 0;
   if (h->pin) hipHostFree(h->pin);
   h->pin = nullptr; h->pin_bytes = 0;
   h->st_l = h->st_r = nullptr; h->st_d = nullptr; h->st_n = h->st_W = h->st_H = 0;
@@ -284,6 +298,11 @@ static void destroy_now(sbm_handle* h) {
     if (h->ev_in[i]) hipEventDestroy(h->ev_in[i]);
     if (h->ev_done[i]) hipEventDestroy(h->ev_done[i]);
   }
+  for (int k = 0; k < 4; k++) {
+    if (h->ev_fq_in[k]) hipEventDestroy(h->ev_fq_in[k]);
+    if (h->ev_fq_done[k]) hipEventDestroy(h->ev_fq_done[k]);
+    if (h->ev_fq_out[k]) hipEventDestroy(h->ev_fq_out[k]);
+  }
   if (h->stream_in) hipStreamDestroy(h->stream_in);
   if (h->stream_out) hipStreamDestroy(h->stream_out);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -313,6 +332,10 @@ int sbm_synchronize(sbm_handle* h) {
   DeviceScope dscope(h->device);
   HIPCHK(h, dscope.enter());
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  while (h->fq_waited != h->fq_submitted) {   // submissions of the asynchronous feed count as pending work too
+    const int st = sbm_wait_oldest(h);
+    if (st != SBM_OK) return st;
+  }
   return SBM_OK;
 }
 
@@ -359,7 +382,9 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
   }
   const size_t npix = (size_t)h->cap_n * W * H;
   if (need_cost && !h->cost) HIPCHK(h, hipMalloc((void**)&h->cost, npix * sizeof(int32_t)));
-  if (need_speckle && !h->labels) {
+  if (need_speckle && !h->spk_nseam) {   // keyed on the LAST buffer of the set: an attempt that failed half way is redone
+    hipFree(h->labels); hipFree(h->counts); hipFree(h->spk_heads); hipFree(h->spk_nheads); hipFree(h->spk_seam);
+    h->labels = h->counts = nullptr; h->spk_heads = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr;
     HIPCHK(h, hipMalloc((void**)&h->labels, npix * sizeof(int32_t)));
     HIPCHK(h, hipMalloc((void**)&h->counts, npix * sizeof(int32_t)));
     HIPCHK(h, hipMalloc((void**)&h->spk_heads, npix * sizeof(uint32_t)));
@@ -481,8 +506,10 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
     if (fast) {
       int xa = 0, xb = 0;
       HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", g_sad_kernel_name);
     } else {
       HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_generic_kernel");
     }
     mark(h, 2);
     if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -748,6 +775,12 @@ int sbm_get_profile(sbm_handle* h, const char* name, float* ms) {
   return SBM_OK;
 }
 
+int sbm_last_kernel_name(sbm_handle* h, char* dst, size_t dst_bytes) {
+  if (!h || !dst || dst_bytes == 0) return SBM_ERR_NULL;
+  snprintf(dst, dst_bytes, "%s", h->last_kernel);
+  return SBM_OK;
+}
+
 int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes) {
   if (!h || !dst) return SBM_ERR_NULL;
   if (!h->have_last) return SBM_ERR_UNSUPPORTED;
@@ -825,17 +858,55 @@ static int ensure_pipe(sbm_handle* h) {
 // works on chunk k while chunk k+1 arrives and chunk k-1 leaves. With pageable caller memory the copies themselves still
 // run one after the other on the calling thread (the runtime stages them), but the compute disappears behind them; with
 // pinned (hipHostMalloc / hipHostRegister) caller memory the two copy directions overlap as well.
+// maps [i0, i1) device -> caller, one transfer per run of maps that are contiguous in the caller's memory
+static hipError_t copy_out_runs(sbm_handle* h, int16_t* const* disp, int i0, int i1, size_t npix1) {
+  for (int i = i0; i < i1;) {
+    int j = i + 1;
+    while (j < i1 && disp[j] == disp[j - 1] + npix1) j++;
+    const hipError_t e = hipMemcpyAsync(disp[i], h->st_d + i * npix1, (size_t)(j - i) * npix1 * 2, hipMemcpyDeviceToHost, h->stream_out);
+    if (e != hipSuccess) return e;
+    i = j;
+  }
+  return hipSuccess;
+}
+
 static int pipelined_enqueue(sbm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int width,
                              int height, int16_t* const* disp) {
   const size_t npix1 = (size_t)width * height;
-  int chunk = 8;
-  while ((n + chunk - 1) / chunk > sbm_handle::kChunks) chunk *= 2;
-  const int nch = (n + chunk - 1) / chunk;
+  // Chunk plan. Small chunks overlap more of the transfers but run the kernels on part-filled launches (8 KITTI pairs cost
+  // 0.36 ms on the device, 64 pairs 1.2 ms), so: a small FIRST chunk (the computation starts after one short transfer), a
+  // small LAST one (only its computation and its maps are left when the inputs have arrived) and large ones in between.
+  // Measured on 64 KITTI pairs from pinned memory (profiles/r03_host_feed.json). SBM_HOST_CHUNK=<pairs>: uniform chunks.
+  static const int chunk_env = [] { const char* e = getenv("SBM_HOST_CHUNK"); return e ? atoi(e) : 0; }();
+  int start[sbm_handle::kChunks + 1];
+  int nch = 0;
+  start[0] = 0;
+  if (chunk_env > 0 || n < 32) {
+    int chunk = chunk_env > 0 ? chunk_env : 8;
+    while ((n + chunk - 1) / chunk > sbm_handle::kChunks) chunk *= 2;
+    for (int i = 0; i < n; i += chunk) start[++nch] = std::min(n, i + chunk);
+  } else {
+    const int edge = 8, mid = n - 2 * edge;
+    int nmid = std::max(1, (mid + 23) / 24);                     // middle chunks of at most 24 pairs
+    nmid = std::min(nmid, sbm_handle::kChunks - 2);
+    start[++nch] = edge;
+    for (int k = 1; k <= nmid; k++) start[++nch] = edge + (int)((long)mid * k / nmid);
+    start[++nch] = n;
+  }
   for (int k = 0; k < nch; k++) {
-    const int i0 = k * chunk, cnt = std::min(chunk, n - i0);
-    for (int i = i0; i < i0 + cnt; i++) {
-      HIPCHK(h, hipMemcpyAsync(h->st_l + i * npix1, left[i], npix1, hipMemcpyHostToDevice, h->stream_in));
-      HIPCHK(h, hipMemcpyAsync(h->st_r + i * npix1, right[i], npix1, hipMemcpyHostToDevice, h->stream_in));
+    const int i0 = start[k], cnt = start[k + 1] - i0;
+    // images that follow each other in the caller's memory (one (n,H,W) array) travel as one transfer per run
+    for (int i = i0; i < i0 + cnt;) {
+      int j = i + 1;
+      while (j < i0 + cnt && left[j] == left[j - 1] + npix1) j++;
+      HIPCHK(h, hipMemcpyAsync(h->st_l + i * npix1, left[i], (size_t)(j - i) * npix1, hipMemcpyHostToDevice, h->stream_in));
+      i = j;
+    }
+    for (int i = i0; i < i0 + cnt;) {
+      int j = i + 1;
+      while (j < i0 + cnt && right[j] == right[j - 1] + npix1) j++;
+      HIPCHK(h, hipMemcpyAsync(h->st_r + i * npix1, right[i], (size_t)(j - i) * npix1, hipMemcpyHostToDevice, h->stream_in));
+      i = j;
     }
     HIPCHK(h, hipEventRecord(h->ev_in[k], h->stream_in));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[k], 0));
@@ -843,15 +914,12 @@ static int pipelined_enqueue(sbm_handle* h, int n, const uint8_t* const* left, c
     if (st != SBM_OK) return st;
     HIPCHK(h, hipEventRecord(h->ev_done[k], h->stream));
     if (k > 0) {   // the previous chunk leaves while this one computes
-      const int j0 = (k - 1) * chunk;
       HIPCHK(h, hipStreamWaitEvent(h->stream_out, h->ev_done[k - 1], 0));
-      for (int i = j0; i < j0 + chunk; i++)
-        HIPCHK(h, hipMemcpyAsync(disp[i], h->st_d + i * npix1, npix1 * 2, hipMemcpyDeviceToHost, h->stream_out));
+      HIPCHK(h, copy_out_runs(h, disp, start[k - 1], start[k], npix1));
     }
   }
   HIPCHK(h, hipStreamWaitEvent(h->stream_out, h->ev_done[nch - 1], 0));
-  for (int i = (nch - 1) * chunk; i < n; i++)
-    HIPCHK(h, hipMemcpyAsync(disp[i], h->st_d + i * npix1, npix1 * 2, hipMemcpyDeviceToHost, h->stream_out));
+  HIPCHK(h, copy_out_runs(h, disp, start[nch - 1], n, npix1));
   return SBM_OK;
 }
 
@@ -868,6 +936,101 @@ static int compute_batch_pipelined(sbm_handle* h, int n, const uint8_t* const* l
   HIPCHK(h, e1);
   HIPCHK(h, e2);
   HIPCHK(h, e3);
+  return SBM_OK;
+}
+
+// ---- asynchronous dense feed -------------------------------------------------------------------------------------
+// What a per-GPU feeder thread uses: batch k+1 is submitted (its inputs start crossing PCIe on the H2D stream) while batch k
+// computes and batch k-1's maps travel back on the D2H stream. Whole batches, no chunking: the kernels run on full launches
+// and in steady state a step costs its slowest leg (profiles/r03_host_feed.json). Caller buffers should be pinned
+// (hipHostMalloc / hipHostRegister) -- pageable memory works but the runtime then copies synchronously.
+// The runtime executes the copies of all streams in the order they were queued (measured: an H2D transfer queued behind a
+// D2H one does not start before it, whatever their streams -- profiles/r03_host_feed.json), and a D2H copy can only run when
+// its batch has been computed. So the maps of submission k are queued for their trip home only AFTER the inputs of
+// submission k+1 (or when somebody waits for k): the inputs of k+1 then cross PCIe while k computes.
+static int fq_flush_pending(sbm_handle* h) {
+  if (!h->fq_pending_dst) return SBM_OK;
+  const unsigned k = h->fq_submitted - 1u, slot = k & 1u, e = k & 3u;
+  HIPCHK(h, hipStreamWaitEvent(h->stream_out, h->ev_fq_done[e], 0));
+  HIPCHK(h, hipMemcpyAsync(h->fq_pending_dst, h->fq_d[slot], h->fq_pending_bytes, hipMemcpyDeviceToHost, h->stream_out));
+  HIPCHK(h, hipEventRecord(h->ev_fq_out[e], h->stream_out));
+  h->fq_pending_dst = nullptr;
+  return SBM_OK;
+}
+
+int sbm_wait_oldest(sbm_handle* h) {
+  if (!h) return SBM_ERR_NULL;
+  if (h->fq_waited == h->fq_submitted) return SBM_OK;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  if (h->fq_waited + 1u == h->fq_submitted) {   // the newest submission: its maps may not have been queued yet
+    const int st = fq_flush_pending(h);
+    if (st != SBM_OK) return st;
+  }
+  HIPCHK(h, hipEventSynchronize(h->ev_fq_out[h->fq_waited & 3u]));
+  h->fq_waited++;
+  return SBM_OK;
+}
+
+int sbm_submit_dense(sbm_handle* h, int n, const uint8_t* left, const uint8_t* right, int width, int height, int16_t* disp) {
+  if (!h || !left || !right || !disp) return SBM_ERR_NULL;
+  if (n <= 0) return SBM_ERR_BATCH;
+  int st = sbm_params_validate(&h->p, width, height);
+  if (st != SBM_OK) return st;
+  DeviceScope dscope(h->device);
+  HIPCHK(h, dscope.enter());
+  st = ensure_pipe(h);
+  if (st != SBM_OK) return st;
+  if (!h->fq_ok) {
+    for (int k = 0; k < 4; k++) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_fq_in[k], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_fq_done[k], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_fq_out[k], hipEventDisableTiming));
+    }
+    h->fq_ok = true;
+  }
+  while (h->fq_submitted - h->fq_waited >= 3u) {   // queue depth: one batch arriving, one computing, one leaving
+    st = sbm_wait_oldest(h);
+    if (st != SBM_OK) return st;
+  }
+  const size_t npix = (size_t)n * width * height;
+  if (!(n <= h->fq_n && width == h->fq_W && height == h->fq_H && h->fq_l[0])) {
+    while (h->fq_waited != h->fq_submitted) {
+      st = sbm_wait_oldest(h);
+      if (st != SBM_OK) return st;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 2; k++) {
+      hipFree(h->fq_l[k]); hipFree(h->fq_r[k]); hipFree(h->fq_d[k]);
+      h->fq_l[k] = h->fq_r[k] = nullptr; h->fq_d[k] = nullptr;
+    }
+    h->fq_n = 0;
+    for (int k = 0; k < 2; k++) {
+      HIPCHK(h, hipMalloc((void**)&h->fq_l[k], npix + 64));
+      HIPCHK(h, hipMalloc((void**)&h->fq_r[k], npix + 64));
+      HIPCHK(h, hipMalloc((void**)&h->fq_d[k], npix * sizeof(int16_t)));
+    }
+    h->fq_n = n; h->fq_W = width; h->fq_H = height;
+  }
+  // submission k uses device staging set k & 1. The set's previous user is submission k-2: its inputs are free once k-2 has
+  // computed, its map buffer once k-2's maps have left -- both are stream dependencies, the host never blocks on them.
+  const unsigned k = h->fq_submitted, slot = k & 1u, e = k & 3u;
+  if (k >= 2 && k - 2 >= h->fq_waited) {
+    HIPCHK(h, hipStreamWaitEvent(h->stream_in, h->ev_fq_done[(k - 2) & 3u], 0));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fq_out[(k - 2) & 3u], 0));
+  }
+  HIPCHK(h, hipMemcpyAsync(h->fq_l[slot], left, npix, hipMemcpyHostToDevice, h->stream_in));
+  HIPCHK(h, hipMemcpyAsync(h->fq_r[slot], right, npix, hipMemcpyHostToDevice, h->stream_in));
+  HIPCHK(h, hipEventRecord(h->ev_fq_in[e], h->stream_in));
+  st = fq_flush_pending(h);                      // the previous submission's maps: queued behind this one's inputs
+  if (st != SBM_OK) return st;
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fq_in[e], 0));
+  st = sbm_compute_device(h, n, h->fq_l[slot], h->fq_r[slot], width, height, h->fq_d[slot], 0);
+  if (st != SBM_OK) return st;
+  HIPCHK(h, hipEventRecord(h->ev_fq_done[e], h->stream));
+  h->fq_pending_dst = disp;
+  h->fq_pending_bytes = npix * sizeof(int16_t);
+  h->fq_submitted++;
   return SBM_OK;
 }
 

@@ -48,6 +48,8 @@ hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t*
 
 // Fast path (interior columns, block size multiple of 3 up to 21, 16-bit sums). Returns hipErrorNotSupported
 // when the configuration is outside its envelope; *xa,*xb receive the column range it covered.
+// name of the SAD kernel instantiation of the calling thread's last launch (template tuple; sbm_last_kernel_name())
+extern thread_local char g_sad_kernel_name[96];
 bool sad_fast_supported(const Geom& g);
 int sad_fast_pfshift(const Geom& g);   // 2 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,

@@ -24,6 +24,7 @@
 // Windows that are not multiples of 3 use 1-column sums (template parameter PW = 1: single-byte pattern, w-1 partners).
 // Envelope (checked on the host, everything else takes the generic kernel): odd w in 5..27, nd <= 256,
 // w*w*2*cap <= 65534 (16-bit sums), 2*(maxS*uniq/100+1) < 65535, valid-ROI rows inside [w/2, H-w/2).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -641,6 +642,8 @@ static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
   constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
   constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
   const size_t lds = (size_t)NWAVES * WSLOT * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
+           NDW, NWAVES, NTERM, PW, a.nd == NDW * NWAVES ? "true" : "false", a.pfshift);
   if (a.nd == NDW * NWAVES)
     hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true>), grid, dim3(64 * NWAVES), lds, s, a);
   else

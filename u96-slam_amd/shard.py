@@ -43,7 +43,9 @@ def scatter_pairs(left, right, n_pairs, shape_hw, src=0, device=None, group=None
         for r in range(world):
             lo, hi = shard_bounds(n_pairs, r, world)
             if r != src and hi > lo:
-                ops += [dist.P2POp(dist.isend, left[lo:hi], r, group), dist.P2POp(dist.isend, right[lo:hi], r, group)]
+                # the transport moves tensors of `device` (nccl: this rank's GPU): a batch that lives elsewhere is staged
+                # block by block; .to() is a no-op for a batch that is already there
+                ops += [dist.P2POp(dist.isend, left[lo:hi].to(device), r, group), dist.P2POp(dist.isend, right[lo:hi].to(device), r, group)]
         reqs = _p2p(ops, group)
         lo, hi = shard_bounds(n_pairs, src, world)
         mine = left[lo:hi].to(device).contiguous(), right[lo:hi].to(device).contiguous()
@@ -124,7 +126,7 @@ def compute_sharded_chunked(compute_fn, left, right, n_pairs, shape_hw, chunk=8,
                     continue
                 a, b = chunk_span(r, t)
                 if b > a:
-                    ops += [dist.P2POp(dist.isend, left[a:b], r, group), dist.P2POp(dist.isend, right[a:b], r, group)]
+                    ops += [dist.P2POp(dist.isend, left[a:b].to(device), r, group), dist.P2POp(dist.isend, right[a:b].to(device), r, group)]
                 a, b = chunk_span(r, t - 2)
                 if t >= 2 and b > a:
                     ops.append(dist.P2POp(dist.irecv, out[a:b].view(torch.uint8), r, group))

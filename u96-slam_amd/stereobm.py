@@ -134,9 +134,12 @@ def load_library():
     L.sbm_compute_batch.argtypes = [vp, ci, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), sz, ci, ci, ctypes.POINTER(vp), sz]
     L.sbm_compute_device.argtypes = [vp, ci, vp, vp, ci, ci, vp, ci]
     L.sbm_synchronize.argtypes = [vp]
+    L.sbm_submit_dense.argtypes = [vp, ci, vp, vp, ci, ci, vp]
+    L.sbm_wait_oldest.argtypes = [vp]
     L.sbm_debug_fetch.argtypes = [vp, ci, vp, sz]
     L.sbm_set_profiling.argtypes = [vp, ci]
     L.sbm_get_profile.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
+    L.sbm_last_kernel_name.argtypes = [vp, ctypes.c_char_p, sz]
     mp = ctypes.POINTER(StereoModel)
     L.sbm_disparity_to_float_device.argtypes = [vp, ci, vp, ci, ci, vp, ci]
     L.sbm_decimate_device.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci]
@@ -185,7 +188,7 @@ class StereoBM:
         L.sbm_params_default(ctypes.byref(self._p), numDisparities, blockSize)
         self._h = ctypes.c_void_p()
         self._device = device
-        self._inflight = None
+        self._inflight = []
         _check(L.sbm_create(ctypes.byref(self._h), ctypes.byref(self._p), device))
 
     @staticmethod
@@ -284,6 +287,22 @@ class StereoBM:
                self._h)
         return out[0] if (single and disparity is None) else out
 
+    def submit_host(self, left, right, disparity):
+        """sbm_submit_dense: queue one dense (n,H,W) uint8 batch in (pinned) host memory; `disparity` (n,H,W) int16 is filled
+        when the matching wait_host() returns. At most three submissions are in flight."""
+        for a, dt in ((left, np.uint8), (right, np.uint8), (disparity, np.int16)):
+            if not isinstance(a, np.ndarray) or a.dtype != dt or a.ndim != 3 or not a.flags.c_contiguous:
+                raise StereoBMError(-2, "submit_host takes C-contiguous (n,H,W) arrays: uint8 images, int16 disparity")
+        if left.shape != right.shape or left.shape != disparity.shape:
+            raise StereoBMError(-2, "All the images must have the same size")
+        n, h, w = left.shape
+        _check(self._L.sbm_submit_dense(self._h, n, left.ctypes.data, right.ctypes.data, w, h, disparity.ctypes.data), self._h)
+        self._inflight.append((left, right, disparity))
+
+    def wait_host(self):
+        """sbm_wait_oldest: block until the oldest outstanding submit_host() has delivered its maps."""
+        _check(self._L.sbm_wait_oldest(self._h), self._h)
+
     def compute_device(self, left, right, disparity=None, sync=True):
         """Device-resident batch: torch CUDA uint8 tensors (n,H,W) or (H,W), contiguous. Returns a torch int16 tensor."""
         import torch
@@ -313,8 +332,23 @@ class StereoBM:
         if not sync:
             # torch's caching allocator only knows its own streams: without this the .contiguous() temporaries and a
             # freshly allocated output could be handed out again while the engine's kernels still use them
-            self._inflight = (left, right, disparity)
+            # (a list: back-to-back asynchronous calls each keep their buffers until the next synchronize())
+            self._inflight.append((left, right, disparity))
+        else:
+            self._inflight.clear()   # a synchronous call drains the engine's stream: earlier asynchronous calls are done too
         return disparity
+
+    def _check_device_images(self, *tensors):
+        """Every image handed to the engine as a raw pointer: CUDA uint8, on the handle's device, (H,W) or (n,H,W)."""
+        import torch
+
+        for t in tensors:
+            if not isinstance(t, torch.Tensor) or t.dtype != torch.uint8 or not t.is_cuda:
+                raise StereoBMError(-2, "images must be CUDA uint8 tensors")
+            if t.device.index != self._device:
+                raise StereoBMError(-20, f"tensor on cuda:{t.device.index}, engine on device {self._device}")
+            if t.dim() not in (2, 3):
+                raise StereoBMError(-2, "expected (H,W) or (n,H,W) images")
 
     def launch_raw(self, n, d_left, d_right, w, h, d_disp, sync=False):
         """Thin call of sbm_compute_device on raw device addresses (used by bench.py's timed loop)."""
@@ -398,9 +432,8 @@ class StereoBM:
         """Stand-alone x-Sobel prefilter of torch CUDA uint8 (n,H,W) or (H,W) frames, cv or RTL flavour."""
         import torch
 
+        self._check_device_images(src)
         src = src.contiguous()
-        if src.dtype != torch.uint8 or not src.is_cuda:
-            raise StereoBMError(-2, "frames must be CUDA uint8 tensors")
         h, w = src.shape[-2], src.shape[-1]
         n = 1 if src.dim() == 2 else src.shape[0]
         out = torch.empty_like(src)
@@ -413,7 +446,8 @@ class StereoBM:
     def _fpga(self, fn, a, b, params):
         import torch
 
-        if a.shape != b.shape or a.dtype != torch.uint8 or b.dtype != torch.uint8 or not a.is_cuda or not b.is_cuda:
+        self._check_device_images(a, b)
+        if a.shape != b.shape:
             raise StereoBMError(-2, "both inputs must be CUDA uint8 tensors of the same shape")
         a, b = a.contiguous(), b.contiguous()
         h, w = a.shape[-2], a.shape[-1]
@@ -459,8 +493,7 @@ class StereoBM:
         per-image maximum) -- the inputs of generateKeypoints2 (src/slam/src/core/GFTT.cpp:41)."""
         import torch
 
-        if img.dtype != torch.uint8 or not img.is_cuda:
-            raise StereoBMError(-2, "frames must be CUDA uint8 tensors")
+        self._check_device_images(img)
         img = img.contiguous()
         h, w = img.shape[-2], img.shape[-1]
         n = 1 if img.dim() == 2 else img.shape[0]
@@ -472,7 +505,7 @@ class StereoBM:
 
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
-        self._inflight = None   # buffers of an asynchronous compute_device may be released now
+        self._inflight.clear()   # buffers of asynchronous compute_device calls may be released now
 
     def stream(self):
         return self._L.sbm_stream(self._h)
@@ -481,6 +514,12 @@ class StereoBM:
         # 0 = off, 1 = sync after every call, 2 = stage events only (no host sync; up to 64 calls per profile() read),
         # 3 = as 2 on every 4th call only
         _check(self._L.sbm_set_profiling(self._h, int(on)), self._h)
+
+    def last_kernel(self):
+        """Template instantiation of the SAD kernel the last compute call launched (sbm_last_kernel_name)."""
+        buf = ctypes.create_string_buffer(128)
+        _check(self._L.sbm_last_kernel_name(self._h, buf, 128), self._h)
+        return buf.value.decode()
 
     def profile(self):
         out = {}
