@@ -7,6 +7,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+python3 "$R/tools/publish_profiles.py" --source-hash > "$OUT/source_hash.txt"   # which engine sources these counters belong to
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 

@@ -15,9 +15,36 @@ def last_json(p):
     return json.loads(lines[-1])
 
 
+def source_hash(root):
+    """sha256 over the engine sources (csrc/*.hip, *.h, include/*.h): tools/profile_round.sh records it on the GPU box next to
+    the counters, so that counters of one build are never published for another."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted((root / "u96-slam_amd" / "csrc").glob("*.hip")) + sorted((root / "u96-slam_amd" / "csrc").glob("*.h")) + sorted((root / "include").glob("*.h"))
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def norm_kernel(name):
+    """rocprofv3's 'void sbm::sad_fast_kernel<64, 2, 5, 3, true>(sbm::FastArgs)' -> the engine's 'sad_fast_kernel<64,2,5,3,true>'."""
+    n = name.replace("void ", "").replace("sbm::", "").replace(" ", "")
+    return n.split("(")[0]
+
+
 def main():
+    if len(sys.argv) == 2 and sys.argv[1] == "--source-hash":
+        print(source_hash(Path(__file__).resolve().parents[1]))
+        return
     run, rnd = Path(sys.argv[1]), sys.argv[2]
     prof = Path(__file__).resolve().parents[1] / "profiles"
+    hf = run / "source_hash.txt"
+    here = source_hash(prof.parent)
+    if not hf.exists() or hf.read_text().strip() != here:
+        sys.exit(f"refusing to publish {run}: its counters were taken on engine sources {hf.read_text().strip() if hf.exists() else '(unrecorded)'}, "
+                 f"the working tree is {here} -- re-run tools/profile_round.sh on this build")
     shutil.copy(run / "summary_kernels.md", prof / f"{rnd}_kitti_b64_kernels.md")
     shutil.copy(run / "summary_pmc.json", prof / f"{rnd}_kitti_b64_pmc.json")
     if (run / "summary_ref640t_kernels.md").exists():
@@ -51,7 +78,12 @@ def main():
         name = next(k for k in pmc if "sad_fast_kernel" in k)
         e = pmc[name]
         W, H, nd = shapes[wl]
-        ent = {"kernel": name, "source": f"profiles/{tag}", "date": stamp, "commit": commit}
+        # `kernel` = the engine's own name of the instantiation the un-profiled bench line of this run launched (bench.py compares it
+        # with sbm_last_kernel_name() of later runs); it must be the kernel the counters were read from
+        eng = bench["roofline"]["kernel"]
+        if norm_kernel(name) != eng.split(" ")[0]:
+            sys.exit(f"{wl}: counters are of {norm_kernel(name)}, the bench line launched {eng}")
+        ent = {"kernel": eng, "rocprof_kernel": name, "source": f"profiles/{tag}", "date": stamp, "commit": commit, "source_hash": here}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             fetch, write = e["FETCH_SIZE"]["mean"], e["WRITE_SIZE"]["mean"]
             ent.update({"bytes_per_launch": int(round((2 * fetch + write) * 1024)), "fetch_size_kb": fetch, "write_size_kb": write,

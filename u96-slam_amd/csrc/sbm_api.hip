@@ -36,7 +36,8 @@ struct sbm_handle {
   uint16_t* vsum;      // column sums of PREFILTER_NORMALIZED_RESPONSE (2 * cap_n * W * H), allocated on first use
   // FPGA-flavour matcher scratch (allocated on first use, sized for fp_n pairs of fp_W x fp_H)
   int fp_n, fp_W, fp_H;
-  uint8_t *fp_pad_l, *fp_pad_r, *fp_xs_l, *fp_xs_r;
+  uint8_t *fp_xs_l, *fp_xs_r;
+  int fp_gen;              // call counter of the FPGA-flavour matcher: generation stamp of its saturation flags
   void* fp_rec;
   int* fp_flag;
   // staging for the host-buffer entry points
@@ -164,8 +165,8 @@ static void free_scratch(sbm_handle* h) {
 }
 
 static void free_fpga(sbm_handle* h) {
-  hipFree(h->fp_pad_l); hipFree(h->fp_pad_r); hipFree(h->fp_xs_l); hipFree(h->fp_xs_r); hipFree(h->fp_rec); hipFree(h->fp_flag);
-  h->fp_pad_l = h->fp_pad_r = h->fp_xs_l = h->fp_xs_r = nullptr; h->fp_rec = nullptr; h->fp_flag = nullptr;
+  hipFree(h->fp_xs_l); hipFree(h->fp_xs_r); hipFree(h->fp_rec); hipFree(h->fp_flag);
+  h->fp_xs_l = h->fp_xs_r = nullptr; h->fp_rec = nullptr; h->fp_flag = nullptr;
   h->fp_n = h->fp_W = h->fp_H = 0;
 }
 
@@ -194,7 +195,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   if (h->labels) b += npix * 14 + (size_t)h->cap_n * h->cap_H * 6;   // labels, counts, head lists, seam lists
   if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
-  b += (size_t)h->fp_n * h->fp_W * h->fp_H * 12 + (size_t)2 * h->fp_n * (h->fp_W + 191) * h->fp_H;
+  b += (size_t)h->fp_n * h->fp_W * h->fp_H * 10;
   return b;
 }
 
@@ -602,15 +603,15 @@ int sbm_fpga_params_validate(const sbm_fpga_params* p) {
 }
 
 static int ensure_fpga(sbm_handle* h, int n, int W, int H, bool need_xs) {
-  const bool fits = n <= h->fp_n && W == h->fp_W && H == h->fp_H && h->fp_pad_l;
+  const bool fits = n <= h->fp_n && W == h->fp_W && H == h->fp_H && h->fp_flag;
   if (!fits) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     free_fpga(h);
-    const size_t padb = (size_t)n * fpga_pitch(W) * H + 64, npix = (size_t)n * W * H;
-    HIPCHK(h, hipMalloc((void**)&h->fp_pad_l, padb));
-    HIPCHK(h, hipMalloc((void**)&h->fp_pad_r, padb));
+    const size_t npix = (size_t)n * W * H;
     HIPCHK(h, hipMalloc(&h->fp_rec, npix * 8));
     HIPCHK(h, hipMalloc((void**)&h->fp_flag, (size_t)n * sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(h->fp_flag, 0, (size_t)n * sizeof(int), h->stream));   // generation stamps: 0 = never saturated
+    h->fp_gen = 0;
     h->fp_n = n; h->fp_W = W; h->fp_H = H;
   }
   if (need_xs && !h->fp_xs_l) {
@@ -632,8 +633,8 @@ int sbm_fpga_bm_device(sbm_handle* h, int n, const void* d_xsbl_l, const void* d
   HIPCHK(h, dscope.enter());
   st = ensure_fpga(h, n, p->width, p->height, false);
   if (st != SBM_OK) return st;
-  HIPCHK(h, launch_fpga_bm((const uint8_t*)d_xsbl_l, (const uint8_t*)d_xsbl_r, h->fp_pad_l, h->fp_pad_r, h->fp_rec, h->fp_flag,
-                           (int16_t*)d_disp, n, *p, h->stream));
+  HIPCHK(h, launch_fpga_bm((const uint8_t*)d_xsbl_l, (const uint8_t*)d_xsbl_r, h->fp_rec, h->fp_flag, ++h->fp_gen, (int16_t*)d_disp, n, *p,
+                           h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
 }
@@ -651,8 +652,7 @@ int sbm_fpga_compute_device(sbm_handle* h, int n, const void* d_left, const void
   if (st != SBM_OK) return st;
   HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_left, h->fp_xs_l, n, p->width, p->height, 1, 31, h->stream));
   HIPCHK(h, launch_prefilter_dense((const uint8_t*)d_right, h->fp_xs_r, n, p->width, p->height, 1, 31, h->stream));
-  HIPCHK(h, launch_fpga_bm(h->fp_xs_l, h->fp_xs_r, h->fp_pad_l, h->fp_pad_r, h->fp_rec, h->fp_flag, (int16_t*)d_disp, n, *p,
-                           h->stream));
+  HIPCHK(h, launch_fpga_bm(h->fp_xs_l, h->fp_xs_r, h->fp_rec, h->fp_flag, ++h->fp_gen, (int16_t*)d_disp, n, *p, h->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
   return SBM_OK;
 }

@@ -77,10 +77,10 @@ hipError_t launch_rect_map(const sbm_rect_cam& cam, int W, int H, int16_t* d_map
 hipError_t launch_rect_remap(const uint8_t* d_src, const int16_t* d_map, uint8_t* d_dst, int n, int W, int H,
                              hipStream_t s);
 
-// FPGA-flavour matcher (sbm_fpga.hip). pad_l/pad_r: n * fpga_pitch(W) * H + 64 bytes each; rec: n*sad_hgt*sad_wdt*8 bytes.
-int fpga_pitch(int W);
-hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, uint8_t* pad_l, uint8_t* pad_r, void* rec, int* flag,
-                          int16_t* disp, int n, const sbm_fpga_params& p, hipStream_t s);
+// FPGA-flavour matcher (sbm_fpga.hip). rec: n*sad_hgt*sad_wdt*8 bytes (touched beyond 128 disparities only); flag: n ints,
+// zero when allocated; gen: grows with every call on these buffers (> 0).
+hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, void* rec, int* flag, int gen, int16_t* disp, int n,
+                          const sbm_fpga_params& p, hipStream_t s);
 
 // GFTT minimum-eigenvalue map of the PL (sbm_gftt.hip): eig = n*H*W uint16, maxv = n uint32 (`Max` register per image).
 hipError_t launch_gftt_eig(const uint8_t* img, uint16_t* eig, unsigned* maxv, int n, int W, int H, hipStream_t s);

@@ -4,7 +4,8 @@
 //
 // Device counterpart of src/dvp/rtl/bm_calc_sad.v:78-149,350-612 (abs-diff, HSAD, SAD), bm_calc_det.v:121-438,
 // bm_calc_frac.v:59-173 + diven.v, bm_calc_upd.v:107-209, bm_calc_uni.v:117-134 / bm_calc.v:312-328, bm_obuf2.v:119-154,
-// scheduled like bm_ibuf.v:143-286 (one pass over the frame per 32 disparities, 8-byte records in between). Index
+// but NOT scheduled like bm_ibuf.v:143-286 / bm_obuf.v (one pass over the frame per 32 disparities with 8-byte records
+// in DRAM in between): up to four phases live in one wavefront's registers and the record is merged there. Index
 // mappings (lane j of phase k <-> disparity 32k+j-1, HSAD column c <-> image column ndisp+c, output sample i at column
 // ndisp+hwsz+1+i) are derived in DESIGN.md (section "FPGA flavour").
 //
@@ -16,8 +17,9 @@
 //           fits 16 bits), window sum = P[l + 2*hwsz] - P[l - 1] through LDS
 //   det     key minimum per quarter of the tournament, the top two rounds literally
 // The 10-bit saturation makes HSAD history dependent, so row segments are only exact while nothing saturates: the
-// segmented launch raises a per-pair flag when a column sum passes 1023 and a second, one-segment launch (which exits
-// immediately when the flag is clear) recomputes such pairs strictly top to bottom.
+// segmented launch stamps a per-pair word with the call's generation number when a column sum passes 1023 and a second,
+// one-segment launch (which exits immediately for unstamped pairs; not launched when wsz * 63 <= 1023) recomputes such
+// pairs strictly top to bottom.
 #include <algorithm>
 
 #include "sbm_common.h"
@@ -29,17 +31,20 @@ typedef unsigned long long u64;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct FpgaArgs {
-  const uint8_t* xl;     // padded x-Sobel planes: row pitch `pitch`, column 0 at byte `padl`
+  const uint8_t* xl;     // dense x-Sobel planes [pair][H][W] (read through range-checked buffer loads: no padded copies)
   const uint8_t* xr;
-  uint2* rec;            // [pair][sad_hgt][sad_wdt] records {min1 | min2 << 16, disp1 | disp2 << 8 | frac << 16}
-  int16_t* disp;         // dense output, pre-filled with 0xFFFF
-  int* flag;             // [pair] saturation seen
-  int W, H, pitch, padl, plane;
+  uint2* rec;            // [pair][sad_hgt][sad_wdt] records {min1 | min2 << 16, disp1 | disp2 << 8 | frac << 16}: only
+                         // between the launches of a disparity range that does not fit one launch (more than 4 phases)
+  int16_t* disp;         // dense output; the kernel writes every pixel (0xFFFF where the RTL keeps the firmware's fill)
+  int* flag;             // [pair] generation number of the last call in which a column sum saturated
+  int gen;
+  int W, H;
   int nd, wsz, hwsz, hsad_wdt, sad_wdt, sad_hgt;
-  int phase, last;
+  int phase0, first, last;   // first phase of this launch; first / last launch of the disparity range
   int uni_enb, uni_mode, uni_thr;
   int seg;               // output rows per segment
   int exact;             // 1: the one-segment launch that only runs for flagged pairs
+  int track_sat;         // wsz * 63 > 1023: a column sum can saturate
 };
 
 __device__ __forceinline__ u32 pk_add(u32 a, u32 b) {
@@ -101,153 +106,232 @@ extern __shared__ __attribute__((aligned(16))) u32 fpga_lds[];
 
 constexpr int FP_NR = 18;        // packed registers: reg r = (lane 34-2r | lane 33-2r << 16), lanes 34 and -1 are padding
 constexpr int FP_XS = 64 + 34;   // LDS row: slot 0 = 0 (prefix left of lane 0), slot 1+l = prefix of lane l
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) {
+  u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+  return __builtin_bit_cast(u32, r);
+}
+
+// One launch = NPH consecutive 32-disparity phases of the RTL's schedule, ALL held in registers by the same wavefront (the
+// FPGA makes one pass over the frame per phase with 8-byte records in DRAM in between -- bm_ibuf.v:143-189, bm_obuf.v --
+// because it has 34 abs-diff lanes; a wavefront has registers for 4 x 34). The record {min1, min2, disp1, disp2, frac}
+// of a pixel is merged phase by phase in registers (bm_calc_upd.v:125-209); only a range of more than 4 phases goes
+// through the record plane, once per 4 phases. The x-Sobel planes are read where they lie: range-checked buffer loads
+// return 0 for the few window bytes of the padding lanes that fall outside the batch, and rows/columns the RTL never
+// writes get the firmware's 0xFFFF from the same kernel.
+template <int NPH>
 __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
   const int lane = threadIdx.x;
   const int pair = blockIdx.z;
-  if (a.exact && a.flag[pair] == 0) return;
+  if (a.exact && a.flag[pair] != a.gen) return;
   const int NV = 64 - 2 * a.hwsz;                 // outputs per strip
   const int c = blockIdx.x * NV + lane;           // HSAD column of this lane
   const bool col_ok = c < a.hsad_wdt;
   const int x = a.nd + min(c, a.hsad_wdt - 1);    // image column (clamped for the idle lanes: their sums are never used)
   const int r0 = blockIdx.y * a.seg, r1 = min(r0 + a.seg, a.sad_hgt);
   if (r0 >= r1) return;
-  const uint8_t* pl = a.xl + (size_t)pair * a.plane + a.padl + x;
-  // window byte t of a lane = R[x - 32k - 33 + t]: t = 34 - j for lane j (disparity 32k + j - 1)
-  const uint8_t* pr = a.xr + (size_t)pair * a.plane + a.padl + x - 32 * a.phase - 33;
+  const size_t plane = (size_t)a.W * a.H;
+  // range-checked descriptors over this pair's planes (+ what follows in the batch, at most 2 GB): the lowest window byte
+  // of the leftmost column lies one byte in front of its row, the highest one of the rightmost column a few behind it
+  const size_t rest = ((size_t)gridDim.z - pair) * plane;
+  const unsigned nrec = (unsigned)(rest < 0x7fffffffull ? rest : 0x7fffffffull);
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xl + pair * plane), 0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xr + pair * plane), 0, nrec, 0x00020000);
+  // window byte t of phase kk = R[x - 32 kk - 33 + t], t = 34 - j for lane j (disparity 32 kk + j - 1). The phases of
+  // this launch read one piece: bytes x - 32 (phase0 + NPH - 1) - 33 ... + 32 (NPH - 1) + 39, phase k at dword 8 (NPH-1-k)
+  constexpr int NU = 8 * (NPH - 1) + 10;
+  const int ubase = x - 32 * (a.phase0 + NPH - 1) - 33;   // (-1 for the first column of the last phase: reads as 0 in pair 0)
   u32* const xrow = fpga_lds;                     // [FP_NR][FP_XS]
 
-  u32 V[FP_NR];
+  u32 V[NPH][FP_NR];
 #pragma unroll
-  for (int r = 0; r < FP_NR; r++) V[r] = 0u;
-  u32 satacc = 0u;
+  for (int k = 0; k < NPH; k++)
+#pragma unroll
+    for (int r = 0; r < FP_NR; r++) V[k][r] = 0u;
+  u32 satmax = 0u;
 
-  // |R[t] - L| for the 36 window bytes of row y, packed like V
-  auto row_ad = [&](int y, u32 (&ad)[FP_NR]) {
-    const uint8_t* rr = pr + (size_t)y * a.pitch;
-    u32 w[10];
-    uint4 q0, q1;
-    uint2 q2;
-    __builtin_memcpy(&q0, rr, 16);
-    __builtin_memcpy(&q1, rr + 16, 16);
-    __builtin_memcpy(&q2, rr + 32, 8);
-    w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w; w[8] = q2.x; w[9] = q2.y;
-    const u32 l = (u32)(pl[(size_t)y * a.pitch] & 63) + 1u;   // +1: a zero pattern byte would be masked by the instruction
+  struct Row { u32 u[NU]; u32 l; };
+  auto fetch = [&](int y) {
+    Row g;
+    // the whole byte offset travels in the vector offset: that is the part the hardware range-checks against the
+    // descriptor (a scalar row offset would not be checked, and the last row of the batch must not be over-read)
+    const int vo = y * a.W + ubase;
+#pragma unroll
+    for (int i = 0; i + 4 <= NU; i += 4) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo + 4 * i, 0, 0);
+      g.u[i] = v.x; g.u[i + 1] = v.y; g.u[i + 2] = v.z; g.u[i + 3] = v.w;
+    }
+    {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vo + 4 * (NU - 2), 0, 0);
+      g.u[NU - 2] = v.x; g.u[NU - 1] = v.y;
+    }
+    g.l = (u32)__builtin_amdgcn_raw_buffer_load_b8(rs_l, y * a.W + x, 0, 0);
+    return g;
+  };
+  // |R[t] - L| for the 36 window bytes of one row and phase, packed like V
+  auto row_ad = [&](const Row& g, const int k, u32 (&ad)[FP_NR]) {
+    const u32 l = (g.l & 63u) + 1u;               // +1: a zero pattern byte would be masked by the instruction
 #pragma unroll
     for (int q = 0; q < 9; q++) {
       // 6 significant bits (bm_calc_sad.v:375,380); the +1 bias cancels in the difference
-      const u32 wq = (w[q] & 0x3f3f3f3fu) + 0x01010101u;
-      const u64 win = ((u64)w[q + 1] << 32) | wq;               // only bytes 0..3 meet a non-masked pattern byte
+      const u32 wq = (g.u[8 * (NPH - 1 - k) + q] & 0x3f3f3f3fu) + 0x01010101u;
+      const u64 win = ((u64)g.u[8 * (NPH - 1 - k) + q + 1] << 32) | wq;   // only bytes 0..3 meet a non-masked pattern byte
       const u64 m = __builtin_amdgcn_mqsad_pk_u16_u8(win, l, 0ull);
       ad[2 * q] = (u32)m;
       ad[2 * q + 1] = (u32)(m >> 32);
     }
   };
-  auto add_row = [&](int y) {                     // bm_calc_sad.v:450-457: + |.|, upper limit 1023
-    u32 ad[FP_NR];
-    row_ad(y, ad);
+  auto add_row = [&](const Row& g) {              // bm_calc_sad.v:450-457: + |.|, upper limit 1023
 #pragma unroll
-    for (int r = 0; r < FP_NR; r++) {
-      const u32 s = pk_add(V[r], ad[r]);
-      const u32 m = pk_min(s, 0x03ff03ffu);
-      satacc |= s ^ m;
-      V[r] = m;
+    for (int k = 0; k < NPH; k++) {
+      u32 ad[FP_NR];
+      row_ad(g, k, ad);
+#pragma unroll
+      for (int r = 0; r < FP_NR; r++) {
+        const u32 sum = pk_add(V[k][r], ad[r]);
+        if (a.track_sat) satmax |= sum;     // a sum is at most 1023 + 63: bit 10 of a half <=> that column passed the limiter
+        V[k][r] = pk_min(sum, 0x03ff03ffu);
+      }
     }
   };
-  auto sub_row = [&](int y) {                     // bm_calc_sad.v:459-462: - |.|, lower limit 0
-    u32 ad[FP_NR];
-    row_ad(y, ad);
+  auto sub_row = [&](const Row& g) {              // bm_calc_sad.v:459-462: - |.|, lower limit 0
 #pragma unroll
-    for (int r = 0; r < FP_NR; r++) V[r] = pk_subs(V[r], ad[r]);
+    for (int k = 0; k < NPH; k++) {
+      u32 ad[FP_NR];
+      row_ad(g, k, ad);
+#pragma unroll
+      for (int r = 0; r < FP_NR; r++) V[k][r] = pk_subs(V[k][r], ad[r]);
+    }
   };
 
-  for (int y = r0; y < r0 + a.wsz - 1; y++) add_row(y);          // rows of the first window but the last
+  {
+    Row g = fetch(r0);
+    for (int y = r0; y < r0 + a.wsz - 1; y++) {   // rows of the first window but the last
+      const Row n = fetch(y + 1);
+      add_row(g);
+      g = n;
+    }
+  }
 
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < FP_NR; r++) xrow[r * FP_XS] = 0u;
   }
-  const int k32 = (a.phase & 7) << 5;
+  const int i = c;                                 // output sample of this lane
+  const bool sample = lane < NV && i < a.sad_wdt;
+  int16_t* const dpair = a.disp + (size_t)pair * plane;
+  // columns left of the first sample and right of the last one, and the rows above / below the SAD rows: 0xFFFF
+  // (fpga.c:105-106); written by the first launch of the segmented pass only
+  const bool fill = a.first && !a.exact;
+  const int col_s = a.nd + a.hwsz + 1;             // image column of sample 0
+  auto fill_row = [&](int yy) {                    // this strip's share of a row that holds no sample at all
+    int16_t* row = dpair + (size_t)yy * a.W;
+    if (blockIdx.x == 0)
+      for (int xx = lane; xx < col_s; xx += 64) row[xx] = (int16_t)-1;
+    if (sample) row[col_s + i] = (int16_t)-1;
+    if (blockIdx.x == gridDim.x - 1)
+      for (int xx = col_s + a.sad_wdt + lane; xx < a.W; xx += 64) row[xx] = (int16_t)-1;
+  };
+  if (fill) {
+    if (r0 == 0)
+      for (int yy = 0; yy < a.hwsz; yy++) fill_row(yy);
+    if (r1 == a.sad_hgt)
+      for (int yy = a.hwsz + a.sad_hgt; yy < a.H; yy++) fill_row(yy);
+  }
+
+  Row ge = fetch(r0 + a.wsz - 1);
   for (int r = r0; r < r1; r++) {
-    add_row(r + a.wsz - 1);
-    // ---- SAD: prefix sums over the lanes, window = P[l + 2*hwsz] - P[l - 1] (bm_calc_sad.v:569-605) -----------------
-    u32 S[FP_NR];
-#pragma unroll
-    for (int q = 0; q < FP_NR; q++) {
-      u32 p = V[q];
-      p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x111, 0xf, 0xf, false);   // row_shr:1
-      p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x112, 0xf, 0xf, false);   // row_shr:2
-      p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x114, 0xf, 0xf, false);   // row_shr:4
-      p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, false);   // row_shr:8
-      p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-      p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-      xrow[q * FP_XS + 1 + lane] = p;
+    add_row(ge);
+    const Row gl = fetch(r);                       // the leaving row, consumed at the end of the iteration
+    if (r + 1 < r1) ge = fetch(r + a.wsz);
+    u32 min1 = 0, min2 = 0, disp1 = 0, disp2 = 0, frac = 0;
+    uint2* rp = a.rec + ((size_t)pair * a.sad_hgt + r) * a.sad_wdt + i;
+    if (!a.first && sample) {                      // a range of more than NPH phases: the record of the earlier launches
+      const uint2 rc = *rp;
+      min1 = rc.x & 0xffffu; min2 = rc.x >> 16; disp1 = rc.y & 0xffu; disp2 = (rc.y >> 8) & 0xffu; frac = (rc.y >> 16) & 0xffu;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < FP_NR; q++) S[q] = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz] - xrow[q * FP_XS + lane];
-
-    const int i = c;                               // output sample of this lane
-    if (lane < NV && i < a.sad_wdt) {
-      // ---- bm_calc_det.v: first minimum of every quarter by keys (value << 16 | idx, idx = lane - 1); reg q holds
-      // lane 34-2q (low half, idx 33-2q) and lane 33-2q (high half, idx 32-2q); quarter m = regs 16-4m-3 .. 16-4m
-      u32 Q[4];
+    for (int k = 0; k < NPH; k++) {
+      // ---- SAD: prefix sums over the lanes, window = P[l + 2*hwsz] - P[l - 1] (bm_calc_sad.v:569-605) ---------------
+      u32 S[FP_NR];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        u32 best = 0xffffffffu;
-#pragma unroll
-        for (int q = 13 - 4 * m; q <= 16 - 4 * m; q++) {
-          best = min(best, (S[q] << 16) | (u32)(33 - 2 * q));
-          best = min(best, (S[q] & 0xffff0000u) | (u32)(32 - 2 * q));
-        }
-        Q[m] = best;
+      for (int q = 0; q < FP_NR; q++) {
+        u32 p = V[k][q];
+        p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x111, 0xf, 0xf, false);   // row_shr:1
+        p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x112, 0xf, 0xf, false);   // row_shr:2
+        p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x114, 0xf, 0xf, false);   // row_shr:4
+        p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, false);   // row_shr:8
+        p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+        p += (u32)__builtin_amdgcn_update_dpp(0, (int)p, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+        xrow[q * FP_XS + 1 + lane] = p;
       }
-      const u32 h0 = min(Q[0], Q[1]), l0 = max(Q[0], Q[1]);      // stage 4: half winners and their victims
-      const u32 h1 = min(Q[2], Q[3]), l1 = max(Q[2], Q[3]);
-      const u32 win = min(h0, h1), c0 = max(h0, h1);             // stage 5: winner, loser of the final
-      const u32 c1 = (l1 >> 16) < (l0 >> 16) ? l1 : l0;          //          better of the two semi-final victims
-      const int i1 = (int)(win & 0xffffu), ia = (int)(c0 & 0xffffu), ib = (int)(c1 & 0xffffu);
-      const bool adj0 = ia == i1 + 1 || i1 == ia + 1, adj1 = ib == i1 + 1 || i1 == ib + 1;
-      const bool pick1 = (((c1 >> 16) < (c0 >> 16)) && !adj1) || adj0;   // stage 6
-      const u32 m2k = pick1 ? c1 : c0;
-      const u32 dmin1 = win >> 16, dmin2 = m2k >> 16;
-      const u32 ddisp1 = (u32)(k32 | i1), ddisp2 = (u32)(k32 | (int)(m2k & 0xffffu));
-      // neighbours of the winner lane jw = i1 + 1: lanes jw - 1 and jw + 1, looked up in the prefix rows
-      auto sad_of_lane = [&](int j) -> u32 {
-        const int q = (34 - j) >> 1, hi = (34 - j) & 1;   // lane 34-2q is the low half
-        const u32 pa = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz], pb = xrow[q * FP_XS + lane];
-        const u32 d = pa - pb;
-        return hi ? (d >> 16) : (d & 0xffffu);
-      };
-      const u32 dl = sad_of_lane(i1), dr = sad_of_lane(i1 + 2);
-      const u32 frac_new = rtl_frac(dmin1, dl, dr);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < FP_NR; q++) S[q] = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz] - xrow[q * FP_XS + lane];
 
-      uint2* rp = a.rec + ((size_t)pair * a.sad_hgt + r) * a.sad_wdt + i;
-      u32 min1, min2, disp1, disp2, frac;
-      if (a.phase == 0) {                          // bm_calc_upd.v:147-154
-        min1 = dmin1; min2 = dmin2; disp1 = ddisp1; disp2 = ddisp2; frac = frac_new;
-      } else {                                     // bm_calc_upd.v:125-209
-        const uint2 rc = *rp;
-        const u32 s1 = rc.x & 0xffffu, s2 = rc.x >> 16, sd1 = rc.y & 0xffu, sd2 = (rc.y >> 8) & 0xffu;
-        frac = (rc.y >> 16) & 0xffu;
-        const bool d1s1 = dmin1 < s1, d2s1 = dmin2 < s1, d1s2 = dmin1 < s2, d2s2 = dmin2 < s2;
-        const bool adj = ddisp1 == ((sd1 + 1u) & 0xffu);
-        min1 = s1; disp1 = sd1; min2 = s2; disp2 = sd2;
-        if (d1s1 && d2s1) {
-          min1 = dmin1; disp1 = ddisp1; min2 = dmin2; disp2 = ddisp2; frac = frac_new;
-        } else if (d1s1 && d2s2) {
-          min1 = dmin1; disp1 = ddisp1; frac = frac_new;
-          min2 = !adj ? s1 : dmin2; disp2 = !adj ? sd1 : ddisp2;
-        } else if (d1s1) {
-          min1 = dmin1; disp1 = ddisp1; frac = frac_new;
-          min2 = !adj ? s1 : s2; disp2 = !adj ? sd1 : sd2;
-        } else if (d1s2 && d2s2) {
-          min2 = !adj ? dmin1 : dmin2; disp2 = !adj ? ddisp1 : ddisp2;
-        } else if (d1s2) {
-          min2 = !adj ? dmin1 : s2; disp2 = !adj ? ddisp1 : sd2;
+      if (sample) {
+        // ---- bm_calc_det.v: first minimum of every quarter by keys (value << 16 | idx, idx = lane - 1); reg q holds
+        // lane 34-2q (low half, idx 33-2q) and lane 33-2q (high half, idx 32-2q); quarter m = regs 16-4m-3 .. 16-4m
+        u32 Q[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          u32 best = 0xffffffffu;
+#pragma unroll
+          for (int q = 13 - 4 * m; q <= 16 - 4 * m; q++) {
+            best = min(best, (S[q] << 16) | (u32)(33 - 2 * q));
+            best = min(best, (S[q] & 0xffff0000u) | (u32)(32 - 2 * q));
+          }
+          Q[m] = best;
+        }
+        const u32 h0 = min(Q[0], Q[1]), l0 = max(Q[0], Q[1]);      // stage 4: half winners and their victims
+        const u32 h1 = min(Q[2], Q[3]), l1 = max(Q[2], Q[3]);
+        const u32 win = min(h0, h1), c0 = max(h0, h1);             // stage 5: winner, loser of the final
+        const u32 c1 = (l1 >> 16) < (l0 >> 16) ? l1 : l0;          //          better of the two semi-final victims
+        const int i1 = (int)(win & 0xffffu), ia = (int)(c0 & 0xffffu), ib = (int)(c1 & 0xffffu);
+        const bool adj0 = ia == i1 + 1 || i1 == ia + 1, adj1 = ib == i1 + 1 || i1 == ib + 1;
+        const bool pick1 = (((c1 >> 16) < (c0 >> 16)) && !adj1) || adj0;   // stage 6
+        const u32 m2k = pick1 ? c1 : c0;
+        const u32 dmin1 = win >> 16, dmin2 = m2k >> 16;
+        const int k32 = ((a.phase0 + k) & 7) << 5;
+        const u32 ddisp1 = (u32)(k32 | i1), ddisp2 = (u32)(k32 | (int)(m2k & 0xffffu));
+        // neighbours of the winner lane jw = i1 + 1: lanes jw - 1 and jw + 1, looked up in the prefix rows
+        auto sad_of_lane = [&](int j) -> u32 {
+          const int q = (34 - j) >> 1, hi = (34 - j) & 1;   // lane 34-2q is the low half
+          const u32 pa = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz], pb = xrow[q * FP_XS + lane];
+          const u32 d = pa - pb;
+          return hi ? (d >> 16) : (d & 0xffffu);
+        };
+        const u32 dl = sad_of_lane(i1), dr = sad_of_lane(i1 + 2);
+        const u32 frac_new = rtl_frac(dmin1, dl, dr);
+
+        if (a.first && k == 0) {                     // bm_calc_upd.v:147-154
+          min1 = dmin1; min2 = dmin2; disp1 = ddisp1; disp2 = ddisp2; frac = frac_new;
+        } else {                                     // bm_calc_upd.v:125-209
+          const u32 s1 = min1, s2 = min2, sd1 = disp1, sd2 = disp2;
+          const bool d1s1 = dmin1 < s1, d2s1 = dmin2 < s1, d1s2 = dmin1 < s2, d2s2 = dmin2 < s2;
+          const bool adj = ddisp1 == ((sd1 + 1u) & 0xffu);
+          if (d1s1 && d2s1) {
+            min1 = dmin1; disp1 = ddisp1; min2 = dmin2; disp2 = ddisp2; frac = frac_new;
+          } else if (d1s1 && d2s2) {
+            min1 = dmin1; disp1 = ddisp1; frac = frac_new;
+            min2 = !adj ? s1 : dmin2; disp2 = !adj ? sd1 : ddisp2;
+          } else if (d1s1) {
+            min1 = dmin1; disp1 = ddisp1; frac = frac_new;
+            min2 = !adj ? s1 : s2; disp2 = !adj ? sd1 : sd2;
+          } else if (d1s2 && d2s2) {
+            min2 = !adj ? dmin1 : dmin2; disp2 = !adj ? ddisp1 : ddisp2;
+          } else if (d1s2) {
+            min2 = !adj ? dmin1 : s2; disp2 = !adj ? ddisp1 : sd2;
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();             // the prefix rows are rewritten by the next phase / output row
+    }
+    int16_t* orow = dpair + (size_t)(a.hwsz + r) * a.W;
+    if (sample) {
       if (!a.last) {
         *rp = make_uint2(min1 | (min2 << 16), disp1 | (disp2 << 8) | (frac << 16));
       } else {
@@ -256,45 +340,32 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
           const u32 ratio = rtl_diven<17, 11>(min1, min2) & 0x3ffu;
           if (ratio > (u32)(a.uni_thr & 0x3ff)) od = of = a.uni_mode ? 0xffu : 0x00u;
         }
-        a.disp[((size_t)pair * a.H + a.hwsz + r) * a.W + a.nd + a.hwsz + 1 + i] = (int16_t)rtl_pack(od, of);
+        orow[col_s + i] = (int16_t)rtl_pack(od, of);
       }
     }
-    __builtin_amdgcn_wave_barrier();               // the prefix rows are rewritten by the next output row
-    if (r + 1 < r1) sub_row(r);
+    if (fill) {                                    // the columns of this row that hold no sample
+      if (blockIdx.x == 0)
+        for (int xx = lane; xx < col_s; xx += 64) orow[xx] = (int16_t)-1;
+      if (blockIdx.x == gridDim.x - 1)
+        for (int xx = col_s + a.sad_wdt + lane; xx < a.W; xx += 64) orow[xx] = (int16_t)-1;
+    }
+    if (r + 1 < r1) sub_row(gl);
   }
-  if (!a.exact && col_ok && satacc) atomicOr(a.flag + pair, 1);
+  if (a.track_sat && !a.exact && col_ok && (satmax & 0x04000400u)) atomicMax(a.flag + pair, a.gen);
 }
 
-// ---- dense plane -> padded plane (row pitch, left pad) so that the window loads never leave the allocation -----------
-__global__ void __launch_bounds__(256) fpga_pad_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H,
-                                                       int pitch, int padl, int plane) {
-  const int y = blockIdx.x, img = blockIdx.y;
-  const uint8_t* s = src + ((size_t)img * H + y) * W;
-  uint8_t* d = dst + (size_t)img * plane + (size_t)y * pitch;
-  for (int xx = threadIdx.x; xx < pitch; xx += 256) {
-    const int sx = xx - padl;
-    d[xx] = (sx >= 0 && sx < W) ? s[sx] : 0;
-  }
-}
-
-int fpga_pitch(int W) { return ((W + 64 + 64 + 63) / 64) * 64; }
-
-// xl/xr: dense n*H*W x-Sobel planes on the device. pad_l/pad_r: scratch of n * fpga_pitch(W) * H + 64 bytes each,
-// rec: n*sad_hgt*sad_wdt uint2, flag: n ints.
-hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, uint8_t* pad_l, uint8_t* pad_r, void* rec, int* flag,
-                          int16_t* disp, int n, const sbm_fpga_params& p, hipStream_t s) {
+// xl/xr: dense n*H*W x-Sobel planes on the device. rec: n*sad_hgt*sad_wdt uint2 (used beyond 128 disparities only),
+// flag: n ints, zero when allocated; gen: a number that grows with every call on these buffers (> 0).
+hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, void* rec, int* flag, int gen, int16_t* disp, int n,
+                          const sbm_fpga_params& p, hipStream_t s) {
   FpgaArgs a;
   const int W = p.width, H = p.height;
-  a.W = W; a.H = H; a.pitch = fpga_pitch(W); a.padl = 64; a.plane = a.pitch * H;
+  a.W = W; a.H = H;
   a.nd = p.num_disparities; a.wsz = p.block_size; a.hwsz = p.block_size >> 1;
   a.hsad_wdt = W - a.nd - 1; a.sad_wdt = a.hsad_wdt - 2 * a.hwsz; a.sad_hgt = H - 2 * a.hwsz;
   a.uni_enb = p.uni_enable; a.uni_mode = p.uni_mode; a.uni_thr = p.uni_threshold;
-  a.xl = pad_l; a.xr = pad_r; a.rec = static_cast<uint2*>(rec); a.disp = disp; a.flag = flag;
-  hipError_t e;
-  if ((e = hipMemsetAsync(disp, 0xFF, (size_t)n * W * H * sizeof(int16_t), s)) != hipSuccess) return e;   // fpga.c:105-106
-  if ((e = hipMemsetAsync(flag, 0, (size_t)n * sizeof(int), s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(fpga_pad_kernel, dim3(H, n), dim3(256), 0, s, xl, pad_l, W, H, a.pitch, a.padl, a.plane);
-  hipLaunchKernelGGL(fpga_pad_kernel, dim3(H, n), dim3(256), 0, s, xr, pad_r, W, H, a.pitch, a.padl, a.plane);
+  a.xl = xl; a.xr = xr; a.rec = static_cast<uint2*>(rec); a.disp = disp; a.flag = flag; a.gen = gen;
+  a.track_sat = a.wsz * 63 > 1023;                 // 6-bit abs-diffs: a column sum of up to 16 rows cannot reach the limiter
   const int NV = 64 - 2 * a.hwsz;
   const int strips = (a.sad_wdt + NV - 1) / NV;
   const int nphase = a.nd >> 5;
@@ -302,14 +373,22 @@ hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, uint8_t* pad_l, 
   int nseg = 1;
   while ((long)strips * nseg * n < 4096 && a.sad_hgt / (nseg + 1) >= 2 * a.wsz) nseg++;
   const size_t lds = (size_t)FP_NR * FP_XS * sizeof(u32);
-  for (int pass = 0; pass < 2; pass++) {         // 0: segmented (exact unless a column sum saturates), 1: flagged pairs, one segment
+  const int nph = nphase >= 4 ? 4 : nphase;        // phases per launch: up to 4 live in one wavefront's registers
+  for (int pass = 0; pass < 2; pass++) {
+    // pass 0: segmented (exact unless a column sum saturates); pass 1: flagged pairs only, one segment top to bottom
     a.exact = pass;
     const int ns = pass ? 1 : nseg;
     a.seg = (a.sad_hgt + ns - 1) / ns;
-    if (pass == 1 && nseg == 1) break;            // the first pass already ran top to bottom
-    for (int k = 0; k < nphase; k++) {
-      a.phase = k; a.last = k == nphase - 1;
-      hipLaunchKernelGGL(fpga_bm_kernel, dim3(strips, (a.sad_hgt + a.seg - 1) / a.seg, n), dim3(64), lds, s, a);
+    if (pass == 1 && (nseg == 1 || !a.track_sat)) break;   // the first pass already ran top to bottom / nothing can saturate
+    const dim3 grid(strips, (a.sad_hgt + a.seg - 1) / a.seg, n);
+    for (int k = 0; k < nphase;) {
+      // the remaining phases in groups of 4, 2 or 1 (3 phases = 2 + 1, 6 = 4 + 2, ...)
+      const int left = nphase - k, grp = left >= 4 && nph == 4 ? 4 : (left >= 2 ? 2 : 1);
+      a.phase0 = k; a.first = k == 0; a.last = k + grp == nphase;
+      if (grp == 4) hipLaunchKernelGGL(fpga_bm_kernel<4>, grid, dim3(64), lds, s, a);
+      else if (grp == 2) hipLaunchKernelGGL(fpga_bm_kernel<2>, grid, dim3(64), lds, s, a);
+      else hipLaunchKernelGGL(fpga_bm_kernel<1>, grid, dim3(64), lds, s, a);
+      k += grp;
     }
   }
   return hipGetLastError();

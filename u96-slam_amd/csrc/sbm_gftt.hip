@@ -6,18 +6,23 @@
 // (rows 2..H-3 of a dense uint16 map, `Max` register); consumer: src/slam/src/core/GFTT.cpp:41-170 via FPGA.cpp:283-291.
 // The RTL takes the square root in a Xilinx CORDIC core whose last bit is unspecified; this kernel takes the exact floor.
 //
-// HBM-bound by construction (1 B read + 2 B written per pixel). Lane = image column, a wavefront marches down a row
-// segment like the RTL's line buffers do: three pixel rows (own column and both neighbours, one unaligned 4-byte load per
-// row) give the Sobel pair of the middle row, the three products meet their horizontal neighbours through DPP wave
-// shifts, and the last three rows of horizontal sums stay in registers for the vertical sum. Lanes 0 and 63 only serve as
+// 1 B read + 2 B written per pixel, but about 50 vector operations per pixel: VALU-bound. Lane = image
+// column, a wavefront marches down a row segment like the RTL's line buffers do. Per pixel row one unaligned 4-byte load
+// gives (left, centre, right); only the row's horizontal difference r - l and its 1-2-1 sum are kept (three rows each,
+// rolling), so a Sobel pair costs three more operations. dx^2 >> 6 and dy^2 >> 6 travel in the two halves of one register
+// through the horizontal 3-sum (two DPP wave shifts + one v_add3_u32 serve both; a 3-sum is at most 3 * 16256 < 2^16) and
+// through the vertical one, where v_pk_add_u16 clamp IS gftt_box.v's 16-bit limiter. Lanes 0 and 63 only serve as
 // neighbours (62 outputs per wavefront).
 #include "sbm_common.h"
 
 namespace sbm {
 
 constexpr int GF_NV = 62;    // output columns per wavefront
-constexpr int GF_SEG = 64;   // output rows per wavefront
 
+typedef unsigned short gu16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gf_pk_add_sat(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(gu16x2, a), __builtin_bit_cast(gu16x2, b)));
+}
 __device__ __forceinline__ unsigned gf_shr1(unsigned v) {   // value of lane-1 (lane 0: 0)
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
@@ -25,84 +30,110 @@ __device__ __forceinline__ unsigned gf_shl1(unsigned v) {   // value of lane+1 (
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
+template <bool WIDE>   // WIDE: W >= 4 (every real image); narrower ones read byte by byte
 __global__ void __launch_bounds__(64) gftt_eig_kernel(const uint8_t* __restrict__ img, uint16_t* __restrict__ eig,
-                                                      unsigned* __restrict__ maxv, int W, int H) {
+                                                      unsigned* __restrict__ maxv, int W, int H, int seg) {
   const int lane = threadIdx.x;
   const int n = blockIdx.z;
   const int x = blockIdx.x * GF_NV + lane - 1;            // lane 0 is the left neighbour of the first output column
-  const int y0 = blockIdx.y * GF_SEG, y1 = min(y0 + GF_SEG, H);
+  const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, H);
   const uint8_t* src = img + (size_t)n * W * H;
   uint16_t* dst = eig + (size_t)n * W * H;
   const bool in_img = x >= 0 && x < W;
   const bool sob_ok = x >= 1 && x <= W - 2;               // gftt_sbl.v: first_r / last_r force the edge samples to 0
+  const unsigned colmask = sob_ok ? 0xffffffffu : 0u;     // gftt_box.v: col_start_r | col_end_r -> 0 (and no Sobel sample)
   const bool writes = lane >= 1 && lane <= GF_NV && in_img;
   const int xl = min(max(x - 1, 0), W - 1), xc = min(max(x, 0), W - 1), xr = min(max(x + 1, 0), W - 1);
 
-  // pixel rows y-1, y, y+1 of the Sobel row in flight: (left, centre, right) each
-  // (one unaligned 4-byte load where the Sobel sample exists and the fourth byte is still inside the image; the edge
-  // lanes -- whose samples are forced to 0 anyway -- and the very last pixels of the image read byte by byte)
-  auto load3 = [&](int y, int& l, int& c, int& r) {
+  // one pixel row -> the raw bytes (left | centre << 8 | right << 16); unpacked into (r - l, l + 2c + r) only when the row
+  // is consumed, three loop iterations after the load was issued (the row loop is one load round trip per row otherwise)
+  // Branch-free where the image is at least 4 pixels wide: every lane loads 4 bytes that lie inside its row -- from
+  // column x-1, or from W-4 with the value shifted down one byte for the last Sobel column x = W-2 (whose fourth byte would
+  // be the next row's, or past the batch); lanes without a Sobel sample load from a clamped column and their value is never
+  // used. A divergent load would make the row loop wait for every load at the branch join.
+  const int xa = min(max(x - 1, 0), max(W - 4, 0));
+  const unsigned sh = sob_ok ? 8u * (unsigned)((x - 1) - xa) : 0u;
+  auto load_raw = [&](int y) -> unsigned {
     const int yy = min(max(y, 0), H - 1);
     const uint8_t* p = src + (size_t)yy * W;
-    if (sob_ok && (x + 2 < W || yy < H - 1)) {
+    if constexpr (WIDE) {
       unsigned v;
-      __builtin_memcpy(&v, p + x - 1, 4);
-      l = (int)(v & 0xffu); c = (int)((v >> 8) & 0xffu); r = (int)((v >> 16) & 0xffu);
-    } else {
-      l = p[xl]; c = p[xc]; r = p[xr];
+      __builtin_memcpy(&v, p + xa, 4);
+      return v;                                             // (shifted by `sh` when it is unpacked: no use right behind the load)
     }
+    return (unsigned)p[xl] | ((unsigned)p[xc] << 8) | ((unsigned)p[xr] << 16);
   };
-  // horizontal 3-sums of the three products of Sobel row ys (0 outside rows 1..H-2 and in the edge columns)
-  auto hsums = [&](int ys, int l0, int c0, int r0, int l1, int r1, int l2, int c2, int r2, unsigned& ha, unsigned& hc, unsigned& hb) {
-    unsigned ax = 0, ay = 0;
-    if (sob_ok && ys >= 1 && ys <= H - 2) {
-      const int dx = (r0 - l0) + 2 * (r1 - l1) + (r2 - l2);
-      const int dy = (l2 - l0) + 2 * (c2 - c0) + (r2 - r0);
-      ax = (unsigned)(dx < 0 ? -dx : dx);
-      ay = (unsigned)(dy < 0 ? -dy : dy);
+  auto unpack_ds = [&](unsigned v, int& d, int& sm) {
+    if constexpr (WIDE) v >>= sh;
+    const int l = (int)(v & 0xffu), c = (int)((v >> 8) & 0xffu), r = (int)((v >> 16) & 0xffu);
+    d = r - l;
+    sm = l + r + 2 * c;
+  };
+  auto load_ds = [&](int y, int& d, int& sm) { unpack_ds(load_raw(y), d, sm); };
+  // horizontal 3-sums of the three products of Sobel row ys (0 outside rows 1..H-2 and in the edge columns):
+  // hac = sum(dx^2 >> 6) | sum(dy^2 >> 6) << 16, hb = sum(|dx dy| >> 6)
+  auto hsums = [&](int ys, int d0, int d1, int d2, int s0, int s2, unsigned& hac, unsigned& hb) {
+    unsigned pac = 0, pb = 0;
+    if (ys >= 1 && ys <= H - 2) {                          // uniform
+      const int dx = d0 + 2 * d1 + d2;                     // (r0-l0) + 2 (r1-l1) + (r2-l2)
+      const int dy = s2 - s0;                              // (l2+2c2+r2) - (l0+2c0+r0)
+      const unsigned vxx = (unsigned)__mul24(dx, dx) >> 6, vyy = (unsigned)__mul24(dy, dy) >> 6;
+      const int xy = __mul24(dx, dy);
+      pb = ((unsigned)(xy < 0 ? -xy : xy) >> 6) & colmask;
+      pac = (vxx | (vyy << 16)) & colmask;
     }
-    const unsigned vxx = (ax * ax) >> 6, vyy = (ay * ay) >> 6, vxy = (ax * ay) >> 6;
-    ha = sob_ok ? gf_shr1(vxx) + vxx + gf_shl1(vxx) : 0u;   // gftt_box.v: col_start_r | col_end_r -> 0
-    hc = sob_ok ? gf_shr1(vyy) + vyy + gf_shl1(vyy) : 0u;
-    hb = sob_ok ? gf_shr1(vxy) + vxy + gf_shl1(vxy) : 0u;
+    // (two-input adds: each folds its wave shift into one v_add_u32_dpp; three terms of at most 16256 per half: no carry
+    // between the halves)
+    hac = ((pac + gf_shr1(pac)) + gf_shl1(pac)) & colmask;
+    hb = ((pb + gf_shr1(pb)) + gf_shl1(pb)) & colmask;
   };
 
-  int pl[3], pc[3], pr[3];                                 // pixel rows ys-1, ys, ys+1 (rolling)
-  unsigned ha[3], hc[3], hb[3];                            // horizontal sums of Sobel rows y-1, y, y+1 (rolling)
+  int d0, d1, d2, s0, s1, s2;                              // pixel rows ys-1, ys, ys+1 (rolling)
+  unsigned hac[3], hb[3];                                  // horizontal sums of Sobel rows y-1, y, y+1 (rolling)
   // prime: Sobel rows y0-1 and y0
-  load3(y0 - 2, pl[0], pc[0], pr[0]);
-  load3(y0 - 1, pl[1], pc[1], pr[1]);
-  load3(y0, pl[2], pc[2], pr[2]);
-  hsums(y0 - 1, pl[0], pc[0], pr[0], pl[1], pr[1], pl[2], pc[2], pr[2], ha[0], hc[0], hb[0]);
-  pl[0] = pl[1]; pc[0] = pc[1]; pr[0] = pr[1]; pl[1] = pl[2]; pc[1] = pc[2]; pr[1] = pr[2];
-  load3(y0 + 1, pl[2], pc[2], pr[2]);
-  hsums(y0, pl[0], pc[0], pr[0], pl[1], pr[1], pl[2], pc[2], pr[2], ha[1], hc[1], hb[1]);
+  load_ds(y0 - 2, d0, s0);
+  load_ds(y0 - 1, d1, s1);
+  load_ds(y0, d2, s2);
+  hsums(y0 - 1, d0, d1, d2, s0, s2, hac[0], hb[0]);
+  d0 = d1; s0 = s1; d1 = d2; s1 = s2;
+  load_ds(y0 + 1, d2, s2);
+  hsums(y0, d0, d1, d2, s0, s2, hac[1], hb[1]);
   unsigned mx = 0;
-  for (int y = y0; y < y1; y++) {
+  unsigned q0 = load_raw(y0 + 2), q1 = load_raw(y0 + 3), q2 = load_raw(y0 + 4);   // three rows in flight
+  // rolling state passed by name (three rows per trip): d/s of pixel rows (ya, yb -> new yc), horizontal sums of Sobel rows
+  // (ha, hb_ -> new hc); nothing is copied between rows
+  auto row = [&](int y, unsigned q, int da, int db, int& dc, int sa, int& sc, unsigned hac_a, unsigned hac_b, unsigned& hac_c,
+                 unsigned hb_a, unsigned hb_b, unsigned& hb_c) {
     // Sobel row y+1 from pixel rows y, y+1, y+2
-    pl[0] = pl[1]; pc[0] = pc[1]; pr[0] = pr[1]; pl[1] = pl[2]; pc[1] = pc[2]; pr[1] = pr[2];
-    load3(y + 2, pl[2], pc[2], pr[2]);
-    hsums(y + 1, pl[0], pc[0], pr[0], pl[1], pr[1], pl[2], pc[2], pr[2], ha[2], hc[2], hb[2]);
+    unpack_ds(q, dc, sc);
+    hsums(y + 1, da, db, dc, sa, sc, hac_c, hb_c);
     unsigned out = 0;
     if (y >= 2 && y <= H - 3) {                            // gftt_obuf.v:295-305: four border lines are never written
-      const unsigned a = min(ha[0] + ha[1] + ha[2], 0xffffu), c = min(hc[0] + hc[1] + hc[2], 0xffffu),
-                     b = min(hb[0] + hb[1] + hb[2], 0xffffu);
-      const unsigned apc = a + c, amc = a > c ? a - c : c - a;
+      const unsigned ac = gf_pk_add_sat(gf_pk_add_sat(hac_a, hac_b), hac_c);      // both 16-bit limiters at once
+      const unsigned a = ac & 0xffffu, c = ac >> 16, b = min(hb_a + hb_b + hb_c, 0xffffu);
+      const unsigned apc = a + c, amc = __builtin_amdgcn_sad_u16(a, c, 0u);        // |a - c| (the high halves are 0)
       const unsigned amc2 = (amc * amc) >> 10, b2 = (b * b) >> 8;   // both operands < 2^16: the squares fit 32 bits
       const unsigned s = min(amc2 + b2, 0x3fffffu);
-      // floor(sqrt(s << 10)): s < 2^22 is exact in float, the estimate is within 1 and its square fits 32 bits
+      // floor(sqrt(s << 10)): s < 2^22 and the factor 1024 are exact in float; the hardware root (v_sqrt_f32, 1 ulp) is
+      // within 0.01 of the true one, so its floor is off by at most one either way and two exact comparisons settle it
       const unsigned rad = s << 10;
-      unsigned r = (unsigned)(__builtin_sqrtf((float)s) * 32.0f);
-      r = min(r, 65535u);
-      if (r * r > rad) r--;
-      if (r < 65535u && (r + 1) * (r + 1) <= rad) r++;
+      unsigned r = min((unsigned)__builtin_amdgcn_sqrtf((float)s * 1024.0f), 65535u);
+      r -= (r * r > rad) ? 1u : 0u;
+      r += (r < 65535u && (r + 1u) * (r + 1u) <= rad) ? 1u : 0u;
       const int e = (int)apc - (int)r;
-      out = e < 0 ? 0u : (e > 0xffff ? 0xffffu : (unsigned)e);
+      out = (unsigned)min(max(e, 0), 0xffff);
     }
     if (writes) dst[(size_t)y * W + x] = (unsigned short)out;
     mx = max(mx, writes ? out : 0u);
-    ha[0] = ha[1]; hc[0] = hc[1]; hb[0] = hb[1];
-    ha[1] = ha[2]; hc[1] = hc[2]; hb[1] = hb[2];
+  };
+  // three rows per trip so that the registers of the loads in flight and of the rolling state are re-used by name, never
+  // copied (a copy of a register that a load has not filled yet is a wait for that load); rows beyond the segment / image
+  // are clamped loads. On entry: (d1, s1), (d2, s2) = pixel rows y, y+1; hac/hb[0], [1] = Sobel rows y-1, y.
+  for (int y = y0; y < y1; y += 3) {
+    row(y, q0, d1, d2, d0, s1, s0, hac[0], hac[1], hac[2], hb[0], hb[1], hb[2]);              // new pixel row -> (d0, s0), Sobel -> [2]
+    q0 = load_raw(y + 5);
+    if (y + 1 < y1) { row(y + 1, q1, d2, d0, d1, s2, s1, hac[1], hac[2], hac[0], hb[1], hb[2], hb[0]); q1 = load_raw(y + 6); }
+    if (y + 2 < y1) { row(y + 2, q2, d0, d1, d2, s0, s2, hac[2], hac[0], hac[1], hb[2], hb[0], hb[1]); q2 = load_raw(y + 7); }
   }
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
   if (lane == 0 && mx) atomicMax(maxv + n, mx);
@@ -111,7 +142,12 @@ __global__ void __launch_bounds__(64) gftt_eig_kernel(const uint8_t* __restrict_
 hipError_t launch_gftt_eig(const uint8_t* img, uint16_t* eig, unsigned* maxv, int n, int W, int H, hipStream_t s) {
   hipError_t e = hipMemsetAsync(maxv, 0, (size_t)n * sizeof(unsigned), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(gftt_eig_kernel, dim3((W + GF_NV - 1) / GF_NV, (H + GF_SEG - 1) / GF_SEG, n), dim3(64), 0, s, img, eig, maxv, W, H);
+  // rows per wavefront: every segment re-reads 4 rows; long segments once the batch fills the chip anyway
+  const int strips = (W + GF_NV - 1) / GF_NV;
+  int seg = 64;
+  while (seg < 256 && (long)strips * ((H + 2 * seg - 1) / (2 * seg)) * n >= 8192) seg *= 2;
+  if (W >= 4) hipLaunchKernelGGL(gftt_eig_kernel<true>, dim3(strips, (H + seg - 1) / seg, n), dim3(64), 0, s, img, eig, maxv, W, H, seg);
+  else hipLaunchKernelGGL(gftt_eig_kernel<false>, dim3(strips, (H + seg - 1) / seg, n), dim3(64), 0, s, img, eig, maxv, W, H, seg);
   return hipGetLastError();
 }
 
