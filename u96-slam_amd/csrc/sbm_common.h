@@ -30,7 +30,8 @@ struct Geom {
 // v_mqsad_pk_u16_u8; padding bytes are 0. sbm_debug_fetch() removes the bias again.
 // With Geom::pfshift = 2 the planes store 4*value+1 (<= 253): every absolute difference, hence every SAD, is a multiple
 // of 4, which leaves the two low bits of the packed 16-bit sums free for a register tag in the interior kernel's
-// winner search (sbm_sad_fast.hip; chosen by sad_fast_pfshift() when 4*maxS still fits 16 bits). The border kernels
+// winner search (sbm_sad_fast.hip; chosen by sad_fast_pfshift() when 4*maxS still fits 16 bits; pfshift = 1: 2*value+1,
+// one tag bit, where only 2*maxS fits). The border kernels
 // take the scale out again when they stage a row.
 constexpr int kPfBias = 1;
 
@@ -51,7 +52,7 @@ hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t*
 // name of the SAD kernel instantiation of the calling thread's last launch (template tuple; sbm_last_kernel_name())
 extern thread_local char g_sad_kernel_name[96];
 bool sad_fast_supported(const Geom& g);
-int sad_fast_pfshift(const Geom& g);   // 2 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
+int sad_fast_pfshift(const Geom& g);   // 2 or 1 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                            int* xa, int* xb, hipStream_t s);
 

@@ -365,7 +365,10 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
       best = ((f & 0x3fffu) << 16) | ((f >> 16) & 63u);
     }
 #else
-    if (NR >= 16 && a.pfshift == 2) {
+    // (one tagged variant per instantiation, chosen by the window: a third alternative in the same loop body makes the
+    // register allocator spill hundreds of bytes in every instantiation)
+    constexpr int TSMAX = WSZ <= 15 ? 2 : 1;
+    if (NR >= 16 && TSMAX == 2 && a.pfshift == 2) {
       // Pre-scaled planes (sbm_common.h): every sum is a multiple of 4, so the two low bits of each packed half can carry
       // a register tag. Registers j, j + NR/4, j + NR/2, j + 3NR/4 (tags 0..3 = the top two bits of the buffer index) are
       // reduced with packed 16-bit minima first -- one OR (a full-rate instruction) and one v_pk_min_u16 per register
@@ -384,6 +387,21 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
       }
       const u32 bt = min(min(b[0], b[1]), min(b[2], b[3]));       // (4 S + tag) << 16 | low index bits
       best = (bt & 0xfffc0000u) | (((bt >> 16) & 3u) * (u32)(2 * NG) + (bt & 0xffffu));
+    } else if (NR >= 16 && TSMAX == 1 && a.pfshift == 1) {
+      // the same with one tag bit (planes hold 2 v + 1: windows whose 4 maxS does not fit 16 bits but 2 maxS does, e.g. 21 x 21
+      // at cap 31): registers j and j + NR/2 meet in one v_pk_min_u16, NR/2 survivors get keys
+      constexpr int NG = NR / 2;
+      u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const u32 tag1 = 0x00010001u;
+#pragma unroll
+      for (int j = 0; j < NG; j++) {
+        const u32 gm = pk_min(S[j], S[j + NG] | tag1);
+        const u32 klo = (gm << 16) | (u32)(2 * j);
+        const u32 khi = (gm & 0xffff0000u) | (u32)(2 * j + 1);
+        b[j & 3] = umin3(b[j & 3], klo, khi);
+      }
+      const u32 bt = min(min(b[0], b[1]), min(b[2], b[3]));       // (2 S + tag) << 16 | low index bits
+      best = (bt & 0xfffe0000u) | (((bt >> 16) & 1u) * (u32)(2 * NG) + (bt & 0xffffu));
     } else {
 #pragma unroll
     for (int g0 = 0; g0 < NR; g0 += 32) {
@@ -607,17 +625,22 @@ bool mqsad_inplace_ok(hipStream_t s) {
   return state[dev] == 1;
 }
 
-// Pre-scaled planes for the tagged winner search: 4 * value + 1 must fit a byte and 4 * maxS + 3 a packed half; the
-// uniqueness envelope is the one of sad_fast_supported() on the scaled sums. SBM_FAST_PFSHIFT=0 turns it off.
+// Pre-scaled planes for the tagged winner search: (value << sh) + 1 must fit a byte and (maxS << sh) + tag a packed half;
+// the uniqueness envelope is the one of sad_fast_supported() on the scaled sums. SBM_FAST_PFSHIFT=0 turns it off, =1 limits
+// it to one tag bit.
 int sad_fast_pfshift(const Geom& g) {
   static const int env = [] { const char* e = getenv("SBM_FAST_PFSHIFT"); return e ? atoi(e) : 2; }();
-  if (env != 2 || !sad_fast_supported(g)) return 0;
+  if (env <= 0 || !sad_fast_supported(g)) return 0;
   const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
-  if (4 * 2 * g.cap + 1 > 255) return 0;
-  if (4 * maxs + 3 > 65535) return 0;
-  if (2 * (4 * (maxs * g.uniq / 100 + 1)) >= 65535) return 0;
-  if ((long)g.tex * 4 > 0x3fffffff) return 0;
-  return 2;
+  // the kernels hold one tagged variant each: two tag bits (4 v + 1) for windows up to 15, one (2 v + 1) above
+  const int sh = std::min(env, g.wsz <= 15 ? 2 : 1);
+  const long f = 1L << sh;
+  if (f * 2 * g.cap + 1 > 255) return 0;
+  if (f * maxs + (f - 1) > 65535) return 0;
+  if (2 * (f * (maxs * g.uniq / 100 + 1)) >= 65535) return 0;
+  if ((long)g.tex * f > 0x3fffffff) return 0;
+  return sh == (g.wsz <= 15 ? 2 : 1) ? sh : 0;
+  return 0;
 }
 
 bool sad_fast_supported(const Geom& g) {
