@@ -52,6 +52,7 @@ hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t*
 // name of the SAD kernel instantiation of the calling thread's last launch (template tuple; sbm_last_kernel_name())
 extern thread_local char g_sad_kernel_name[96];
 bool sad_fast_supported(const Geom& g);
+bool mqsad_inplace_ok(hipStream_t s);   // device self-test behind the in-place v_mqsad accumulate (cached per device)
 int sad_fast_pfshift(const Geom& g);   // 2 or 1 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                            int* xa, int* xb, hipStream_t s);

@@ -209,7 +209,11 @@ __global__ void __launch_bounds__(256) sad_border_kernel(BorderArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char border_lds[];
 
-template <int W2>
+// INPLACE: the vertical sums are accumulated in place (v_mqsad_pk_u16_u8 with vdst == src2: right on gfx950, checked on the
+// device by mqsad_inplace_ok() before it is used, see sbm_sad_fast.hip) -- one array of NVC register pairs instead of two
+// in ping-pong. At w = 21 that is 76 instead of 136 VGPRs: the wavefront fits beside four 100-VGPR interior wavefronts of a
+// SIMD from the start of the launch instead of waiting for two of them to retire.
+template <int W2, bool INPLACE>
 __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
   // these wavefronts are latency-bound and share their SIMDs with the VALU-bound interior kernel: let them issue first
   __builtin_amdgcn_s_setprio(3);
@@ -290,10 +294,13 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
   }
   // vertical sums, packed 4 x u16 per virtual column, in ping-pong (mqsad may not overwrite a source): an entering
   // row maps CA -> CB through the free accumulate, the leaving row maps CB -> CA with plain subtractions
-  uint2 CA[NVC];
+  uint2 CA[INPLACE ? 1 : NVC];
   u64 CB[NVC];
 #pragma unroll
-  for (int v = 0; v < NVC; v++) CA[v] = make_uint2(0u, 0u);
+  for (int v = 0; v < NVC; v++) {
+    if constexpr (INPLACE) CB[v] = 0ull;
+    else CA[v] = make_uint2(0u, 0u);
+  }
   int Ct[2] = {0, 0};   // texture: this thread's entries e = tid, tid + T of the njobs*NVC (job, virtual column) pairs
 
   struct Staged { u64 r[RPT]; unsigned char l[2]; };
@@ -332,7 +339,17 @@ __global__ void __launch_bounds__(128) sad_border2_kernel(BorderArgs a) {
       for (int v = 0; v < NVC; v++) {
         const unsigned l = lb[v];
         const u64 win = *reinterpret_cast<const u64*>(rbb + off[v]);
-        if (mode == 0) {
+        if constexpr (INPLACE) {
+          if (mode != 1) {
+            asm("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(CB[v]) : "v"(win), "v"(l));
+          } else {
+            const uint2 t = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, l, 0ull));
+            uint2 cb = __builtin_bit_cast(uint2, CB[v]);
+            cb.x -= t.x;   // no u16 borrows: sums are exact
+            cb.y -= t.y;
+            CB[v] = __builtin_bit_cast(u64, cb);
+          }
+        } else if (mode == 0) {
           CB[v] = __builtin_amdgcn_mqsad_pk_u16_u8(win, l, __builtin_bit_cast(u64, CA[v]));
         } else if (mode == 2) {
           CA[v] = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, l, CB[v]));
@@ -576,7 +593,9 @@ hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* 
                        (size_t)2 * njobs * g.w2 * 4 + (size_t)2 * 2 * njobs * NVC + 16;
     dim3 grid2(nblocks, g.n);
     dim3 block2(64 * ((2 * nq + 63) / 64));
-#define SBM_B2(W) case W: hipLaunchKernelGGL(sad_border2_kernel<W>, grid2, block2, lds, s, a); break;
+    const bool inplace = mqsad_inplace_ok(s);
+#define SBM_B2(W) case W: if (inplace) hipLaunchKernelGGL((sad_border2_kernel<W, true>), grid2, block2, lds, s, a); \
+                          else hipLaunchKernelGGL((sad_border2_kernel<W, false>), grid2, block2, lds, s, a); break;
     switch (g.w2) {   // every odd window 5..27
       SBM_B2(2) SBM_B2(3) SBM_B2(4) SBM_B2(5) SBM_B2(6) SBM_B2(7) SBM_B2(8) SBM_B2(9) SBM_B2(10) SBM_B2(11) SBM_B2(12) SBM_B2(13)
       default: return hipErrorInvalidValue;
