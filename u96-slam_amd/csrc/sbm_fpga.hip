@@ -152,23 +152,47 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
     for (int r = 0; r < FP_NR; r++) V[k][r] = 0u;
   u32 satmax = 0u;
 
-  struct Row { u32 u[NU]; u32 l; };
+  struct Row { u32 u[NU]; u32 l; int delta; };   // delta: wanted byte t = loaded byte t + delta (0 but for the few clamped lanes)
   auto fetch = [&](int y) {
     Row g;
-    // the whole byte offset travels in the vector offset: that is the part the hardware range-checks against the
-    // descriptor (a scalar row offset would not be checked, and the last row of the batch must not be over-read)
+    // Loads never leave the frame's descriptor: a range check that fails zeroes the WHOLE 16- / 8-byte load, and two kinds
+    // of pieces would straddle -- HSAD column 0 of the launch that holds the last phase starts one byte in front of its row
+    // (offset -1 in row 0 of a frame), the last columns of the last row of the LAST frame end a few bytes behind the
+    // batch (only bytes of padding lanes lie outside, but they share loads with real ones). So the piece is loaded from a
+    // start clamped into the descriptor and, in the few wavefronts where a lane was clamped (wave-uniform test), rotated
+    // back into place byte-wise; what falls outside reads as 0, like the zero-padded copies of rounds 1-2.
     const int vo = y * a.W + ubase;
+    const int vs = min(max(vo, 0), (int)nrec - 4 * NU);
 #pragma unroll
     for (int i = 0; i + 4 <= NU; i += 4) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo + 4 * i, 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vs + 4 * i, 0, 0);
       g.u[i] = v.x; g.u[i + 1] = v.y; g.u[i + 2] = v.z; g.u[i + 3] = v.w;
     }
     {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vo + 4 * (NU - 2), 0, 0);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vs + 4 * (NU - 2), 0, 0);
       g.u[NU - 2] = v.x; g.u[NU - 1] = v.y;
     }
     g.l = (u32)__builtin_amdgcn_raw_buffer_load_b8(rs_l, y * a.W + x, 0, 0);
+    g.delta = vo - vs;                             // -1 <= delta <= 7
     return g;
+  };
+  // rotate a clamped piece back into place, where it is consumed (the loads have landed by then: done right behind the
+  // loads, the branch join made every row wait for its own loads and cost 7 %)
+  auto settle = [&](Row& g) {
+    if (__builtin_amdgcn_ballot_w64(g.delta != 0) != 0ull) {
+      const int dq = g.delta >> 2;                 // -1, 0 or 1 (arithmetic shift)
+      const u32 sh = (u32)g.delta & 3u;
+      u32 r[NU];
+#pragma unroll
+      for (int i = 0; i < NU; i++) {
+        const u32 m1 = i >= 1 ? g.u[i - 1] : 0u, p0 = g.u[i], p1 = i + 1 < NU ? g.u[i + 1] : 0u, p2 = i + 2 < NU ? g.u[i + 2] : 0u;
+        const u32 lo = dq < 0 ? m1 : (dq == 0 ? p0 : p1), hi = dq < 0 ? p0 : (dq == 0 ? p1 : p2);
+        r[i] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      }
+#pragma unroll
+      for (int i = 0; i < NU; i++) g.u[i] = r[i];
+      g.delta = 0;
+    }
   };
   // |R[t] - L| for the 36 window bytes of one row and phase, packed like V
   auto row_ad = [&](const Row& g, const int k, u32 (&ad)[FP_NR]) {
@@ -183,7 +207,8 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       ad[2 * q + 1] = (u32)(m >> 32);
     }
   };
-  auto add_row = [&](const Row& g) {              // bm_calc_sad.v:450-457: + |.|, upper limit 1023
+  auto add_row = [&](Row& g) {                    // bm_calc_sad.v:450-457: + |.|, upper limit 1023
+    settle(g);
 #pragma unroll
     for (int k = 0; k < NPH; k++) {
       u32 ad[FP_NR];
@@ -196,7 +221,8 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       }
     }
   };
-  auto sub_row = [&](const Row& g) {              // bm_calc_sad.v:459-462: - |.|, lower limit 0
+  auto sub_row = [&](Row& g) {                    // bm_calc_sad.v:459-462: - |.|, lower limit 0
+    settle(g);
 #pragma unroll
     for (int k = 0; k < NPH; k++) {
       u32 ad[FP_NR];
@@ -209,7 +235,7 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
   {
     Row g = fetch(r0);
     for (int y = r0; y < r0 + a.wsz - 1; y++) {   // rows of the first window but the last
-      const Row n = fetch(y + 1);
+      Row n = fetch(y + 1);
       add_row(g);
       g = n;
     }
@@ -244,7 +270,7 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
   Row ge = fetch(r0 + a.wsz - 1);
   for (int r = r0; r < r1; r++) {
     add_row(ge);
-    const Row gl = fetch(r);                       // the leaving row, consumed at the end of the iteration
+    Row gl = fetch(r);                             // the leaving row, consumed at the end of the iteration
     if (r + 1 < r1) ge = fetch(r + a.wsz);
     u32 min1 = 0, min2 = 0, disp1 = 0, disp2 = 0, frac = 0;
     uint2* rp = a.rec + ((size_t)pair * a.sad_hgt + r) * a.sad_wdt + i;
