@@ -92,3 +92,23 @@ def test_async_dense_feed_matches_the_synchronous_call():
         assert np.array_equal(hd.numpy(), ref)
         assert np.array_equal(bm.compute(L, R), ref)
     bm.wait_host()           # nothing outstanding: returns at once
+
+
+@pytest.mark.parametrize("env,kernel", [
+    ({"SBM_FAST_INPLACE": "0"}, "sad_fast_pp_kernel<64,2,5,3,true> pfshift=2"),      # two-accumulator fallback build (round-2 layout)
+    ({"SBM_FAST_MODE": "0"}, "sad_fast_kernel<64,2,5,3,true> pfshift=2"),             # in place, two cooperating wavefronts
+    ({"SBM_FAST_PFSHIFT": "0"}, "sad_fast_kernel<128,1,5,3,true> pfshift=0"),         # unscaled planes, plain key search
+    ({"SBM_FAST_PFSHIFT": "1"}, "sad_fast_kernel<128,1,5,3,true> pfshift=0"),         # w 15 kernels hold the two-bit variant only
+])
+def test_engine_variants_are_bit_exact(env, kernel):
+    """Every selectable variant of the interior kernel against the oracle on the bench workload (the engine reads these
+    switches once per process, hence the subprocess): the fallback that runs when the device self-test of the in-place
+    v_mqsad accumulate fails must be as exact as the default."""
+    j = _run(["--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "8", "--check"], env=env)
+    assert j["roofline"]["kernel"] == kernel
+    assert j["cpu_baseline"]["bit_exact_vs_gpu"] is True
+
+
+def test_reference_window_uses_one_tag_bit():
+    j = _run(["--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "8", "--check", "--workload", "ref640"])
+    assert j["roofline"]["kernel"] == "sad_fast_kernel<64,1,7,3,true> pfshift=1" and j["cpu_baseline"]["bit_exact_vs_gpu"] is True
