@@ -31,7 +31,7 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["bit_exact_vs_gpu"] is True
     assert cb["opencv"].startswith(("cv2 ", "unavailable"))      # the probe outcome is always recorded
     # the launched SAD kernel is named (template tuple) and the per-step distribution is reported
-    assert j["roofline"]["kernel"].startswith("sad_fast_kernel<128,1,5,3,true>")
+    assert j["roofline"]["kernel"].startswith("sad_fast_kernel<128,1,5,3,true,true>")
     assert 0 < j["ms_per_step_min"] <= j["ms_per_step_median"]
     # counters from the committed profile are only attached to the kernel they were measured on
     assert (j["roofline"]["traffic"] is not None) != ("traffic_reason" in j["roofline"]) or j["roofline"]["traffic"] is None
@@ -95,10 +95,11 @@ def test_async_dense_feed_matches_the_synchronous_call():
 
 
 @pytest.mark.parametrize("env,kernel", [
-    ({"SBM_FAST_INPLACE": "0"}, "sad_fast_pp_kernel<64,2,5,3,true> pfshift=2"),      # two-accumulator fallback build (round-2 layout)
-    ({"SBM_FAST_MODE": "0"}, "sad_fast_kernel<64,2,5,3,true> pfshift=2"),             # in place, two cooperating wavefronts
-    ({"SBM_FAST_PFSHIFT": "0"}, "sad_fast_kernel<128,1,5,3,true> pfshift=0"),         # unscaled planes, plain key search
-    ({"SBM_FAST_PFSHIFT": "1"}, "sad_fast_kernel<128,1,5,3,true> pfshift=0"),         # w 15 kernels hold the two-bit variant only
+    ({"SBM_FAST_INPLACE": "0"}, "sad_fast_pp_kernel<64,2,5,3,true,true> pfshift=2"),      # two-accumulator fallback build (round-2 layout)
+    ({"SBM_FAST_MODE": "0"}, "sad_fast_kernel<64,2,5,3,true,true> pfshift=2"),             # in place, two cooperating wavefronts
+    ({"SBM_FAST_PFSHIFT": "0"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),         # unscaled planes, plain key search
+    ({"SBM_FAST_PFSHIFT": "1"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),         # w 15 kernels hold the two-bit variant only
+    ({"SBM_FAST_CS3": "0"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=2"),             # plain strips only (no column stride 3)
 ])
 def test_engine_variants_are_bit_exact(env, kernel):
     """Every selectable variant of the interior kernel against the oracle on the bench workload (the engine reads these
@@ -111,4 +112,4 @@ def test_engine_variants_are_bit_exact(env, kernel):
 
 def test_reference_window_uses_one_tag_bit():
     j = _run(["--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "8", "--check", "--workload", "ref640"])
-    assert j["roofline"]["kernel"] == "sad_fast_kernel<64,1,7,3,true> pfshift=1" and j["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    assert j["roofline"]["kernel"] == "sad_fast_kernel<64,1,7,3,true,true> pfshift=1" and j["cpu_baseline"]["bit_exact_vs_gpu"] is True

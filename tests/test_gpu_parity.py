@@ -545,6 +545,32 @@ def test_rows_wider_than_4096(pkg, oracle, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cs3", ["1", "0"])
+@pytest.mark.parametrize("cfg", [
+    # (nd, window, H, interior columns, pairs): interior columns = W - nd - (window - 1) around the tiling of the interior
+    # kernel -- triples of column-stride-3 strips cover 3 * (65 - window / 3) columns, plain strips 67 - window each
+    (64, 15, 60, 180, 2), (64, 15, 60, 181, 1), (64, 15, 60, 179, 1), (64, 15, 60, 232, 1), (64, 15, 60, 233, 1),
+    (64, 15, 60, 285, 1), (64, 15, 60, 360, 1), (64, 15, 60, 52, 1), (64, 15, 60, 1, 1), (128, 15, 50, 465, 2),
+    (64, 21, 70, 174, 1), (64, 21, 70, 175, 1), (64, 21, 70, 267, 1), (32, 9, 40, 186, 2), (32, 9, 40, 187, 1),
+    (64, 27, 80, 168, 1), (64, 27, 80, 250, 1), (96, 15, 48, 200, 1), (176, 9, 40, 400, 1), (256, 21, 70, 350, 1),
+])
+def test_interior_strip_tilings(pkg, oracle, cs3, cfg, monkeypatch):
+    """Interior kernel on widths that put the end of the interior columns on, just before and just behind the boundaries of its
+    strip tiling (column-stride-3 triples + plain remainder strips; SBM_FAST_CS3=0: plain strips only), windows 9 / 15 / 21 / 27,
+    one and several cooperating disparity wavefronts, a masked disparity count: every stage against the oracle."""
+    from u96_slam_amd import synth
+
+    monkeypatch.setenv("SBM_FAST_CS3", cs3)
+    nd, wsz, H, ncols, n = cfg
+    W = ncols + nd + wsz - 1
+    L, R = synth.make_batch(77, n, W, H, min(nd, 64))
+    kw = dict(num_disparities=nd, block_size=wsz, texture_threshold=10, uniqueness_ratio=10, speckle_window_size=50,
+              speckle_range=32, disp12_max_diff=1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nsub", ["1", "2", "4"])
 @pytest.mark.parametrize("cfg", [(64, 21, 480, 640, 2), (64, 15, 133, 300, 3), (32, 9, 97, 200, 3), (32, 11, 64, 180, 1),
                                  (48, 13, 77, 260, 2), (16, 5, 50, 120, 4)])

@@ -21,6 +21,13 @@
 //   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan),
 //               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree; per-wavefront
 //               results merged through LDS, one wavefront (alternating per row) finishes and stores.
+// Column stride (template parameter CS, windows that are multiples of 3): with CS = 3 lane i takes column base + 3 i, so the
+// partners of the horizontal window V(c), V(c+3), ... are the NEXT LANES and only NTERM - 1 lanes of a wavefront produce
+// nothing (w 15: 60 of 64 lanes useful instead of 52; w 21: 58 instead of 46). Three such wavefronts (bases b, b+1, b+2)
+// tile 3 * (65 - NTERM) contiguous columns; they are ordinary, independent strips. The right row piece a wavefront stages
+// grows from 64 + nd to 190 + nd bytes (window reads at a lane stride of 48 bytes: still conflict-free), nothing else
+// changes. Columns left over by the last full triple take CS = 1 strips -- both bodies live in one kernel, chosen by a
+// workgroup-uniform branch on the strip index.
 // Windows that are not multiples of 3 use 1-column sums (template parameter PW = 1: single-byte pattern, w-1 partners).
 // Envelope (checked on the host, everything else takes the generic kernel): odd w in 5..27, nd <= 256,
 // w*w*2*cap <= 65534 (16-bit sums), 2*(maxS*uniq/100+1) < 65535, valid-ROI rows inside [w/2, H-w/2).
@@ -42,6 +49,7 @@
 
 #if SBM_FAST_PINGPONG   // second build of this file (sbm_sad_fast_pp.hip): same kernels with two accumulator arrays
 #define sad_fast_kernel sad_fast_pp_kernel
+#define sad_fast_strip sad_fast_pp_strip
 #define launch_sad_fast launch_sad_fast_pp
 #define FastArgs FastArgsPP
 #define fast_lds fast_pp_lds
@@ -64,6 +72,7 @@ struct FastArgs {
   int row0, row1;            // rows [row0,row1)
   int segrow[34];            // row segment k = rows [segrow[k], segrow[k+1]); long segments first, short ones last
   int strips, nseg, npairs;  // grid decomposition (1-D grid of strips*nseg*npairs workgroups)
+  int strips3;               // the first strips3 strips (a multiple of 3) have column stride 3, the others stride 1
   int uniq_plain;            // 8 * (maxS * uniq / 100 + 1) fits 16 bits: deficit partial sums need no saturating adds
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
   int pfshift;               // the planes hold (value << pfshift) + 1: every sum below is scaled by 1 << pfshift (0 or 2)
@@ -118,59 +127,49 @@ extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NS
 #define SBM_FAST_WPE1 4
 #endif
 #endif
-template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND>
-__global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_kernel(FastArgs a) {
+// LDS carve-up of one wavefront in 16-byte slots, shared by the kernel and its launcher
+template <int NDW, int NTERM, int PW, int CS>
+struct FastLds {
+  static constexpr int NQ = NDW / 4;
+  static constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
+  // staging: slot p holds bytes p..p+15 of the right row piece; the last window read of lane 63 is slot
+  // CS*63 + 4 + 16 * (4 * (NCH - 1) + 3)
+  static constexpr int NSLOT = ((CS * 63 + 4 + 16 * (4 * (NCH - 1) + 3) + 1) + 63) / 64 * 64;
+  static constexpr int KS = CS == 3 ? 1 : PW;  // lane distance between two partners of the horizontal window
+  // horizontal exchange: XCH quads at a time, XS entries per quad pair (64 lanes + the KS*(NTERM-1) halo)
+  static constexpr int XCH = NQ < 8 ? NQ : 8;
+  static constexpr int XS = 64 + KS * (NTERM - 1);
+  static constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
+  static constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
+  static_assert(CS == 1 || (CS == 3 && PW == 3), "column stride 3 goes with 3-column sums");
+};
+
+// One strip of one row segment of one pair: lane i works on column cbase + CS * i (relative to lofs).
+template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
+__device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbase, const int segi, const int pair) {
+  using L = FastLds<NDW, NTERM, PW, CS>;
   constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
   constexpr int NR = NDW / 2;           // packed pair registers
-  constexpr int NCH = (NQ + 15) / 16;   // chunks of 16 quads
-  constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
+  constexpr int NSLOT = L::NSLOT;
   constexpr int NIT = NSLOT / 64;
   // PW = columns per vertical sum (the mqsad pattern width): 3 when the window is a multiple of 3, else 1
   constexpr int WSZ = PW * NTERM, W2 = WSZ / 2;
-  constexpr int NV = 64 - (WSZ - PW);   // lanes that produce an output
-  // horizontal exchange through LDS: XCH quads at a time, XS u64 entries per quad (64 lanes + the 3*(NTERM-1) halo)
-  constexpr int XCH = NQ < 8 ? NQ : 8;
-  constexpr int XS = 64 + PW * (NTERM - 1);
-  constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
+  constexpr int KS = L::KS;
+  constexpr int NV = 64 - KS * (NTERM - 1);   // lanes that produce an output
+  constexpr int XCH = L::XCH, XS = L::XS;
 
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int d0 = wv * NDW;                              // first buffer index of this wavefront
-  // XCD-aware decode of the 1-D workgroup id: consecutive ids go round-robin over the 8 XCDs (each with its own
-  // 4 MiB L2), so give XCD k the pairs k, k+8, ...: all strips and row segments of a pair then share one L2.
-  // (Placement only affects speed; any mapping is correct.)
-  // Row segments are the slowest-varying index and get shorter towards the end of the grid: every segment pays w-1
-  // priming rows, so few long segments keep that overhead low while the short last ones keep the tail of the launch
-  // (CUs idling while the last workgroups finish) short.
-  const int bpp = a.strips;                             // workgroups per pair and segment
-  int strip, segi, pair;
-  {
-    const int per_seg = a.strips * a.npairs;
-    segi = blockIdx.x / per_seg;
-    const int b = blockIdx.x - segi * per_seg;
-    const int full = (a.npairs / 8) * 8 * bpp;          // ids covered by complete groups of 8 pairs
-    int p, inner;
-    if (b < full) {
-      const int xcd = b & 7, k = b >> 3;
-      p = (k / bpp) * 8 + xcd;
-      inner = k % bpp;
-    } else {
-      const int r = b - full;
-      p = (a.npairs / 8) * 8 + r / bpp;
-      inner = r % bpp;
-    }
-    pair = p;
-    strip = inner;
-  }
-  const int c = strip * NV + lane;                      // this lane's column (relative to lofs): V covers c..c+2
+  const int c = cbase + CS * lane;                      // this lane's column (relative to lofs): V covers c..c+2
   const int xc = c + W2;                                // centre column this lane produces
   const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
   const int ys = a.segrow[segi];
   const int ye = a.segrow[segi + 1];
   // wavefront-uniform bases (scalar registers; the per-row step is scalar arithmetic) + this lane's 32-bit offset
-  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + strip * NV;  // left bytes: + lane
+  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + cbase;  // left bytes: + CS * lane
   // right piece of the wavefront: window of buffer index d starts at rofs + c + d
-  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + strip * NV + d0;
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + cbase + d0;
   const unsigned lane_u = (unsigned)lane;
   // raw buffer descriptors over the rest of this pair's planes (rows of one pair are < 2^31 bytes apart)
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pl), 0, 0x7fffffff, 0x00020000);
@@ -178,7 +177,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
   // LDS carve-up (16-byte units): per wavefront one region of WSLOT slots that serves first as the staging area of a
   // row (apply) and then as the exchange area of the horizontal window -- never live together, and a wavefront's LDS
   // operations execute in order -- followed by the WTA merge area of the workgroup.
-  constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
+  constexpr int WSLOT = L::WSLOT;
   uint4* const stage_lds = fast_lds + wv * WSLOT;
   uint4* const xq = stage_lds;                                          // [XCH/2 quad pairs][XS lanes], 8 x u16 each
   u32* const xt = reinterpret_cast<u32*>(xq + (XCH / 2) * XS);          // [XS] texture column sums
@@ -221,7 +220,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(it * 64 + lane_u), rowoff, 0);
       g.r[it] = make_uint4(v.x, v.y, v.z, v.w);
     }
-    g.l = __builtin_amdgcn_raw_buffer_load_b32(rs_l, (int)lane_u, rowoff, 0);
+    g.l = __builtin_amdgcn_raw_buffer_load_b32(rs_l, (int)(CS * lane_u), rowoff, 0);
     return g;
   };
   // mode 0: VB = VA + row (enter)   mode 1: VA = VB - row (leave)   mode 2: VA = VB + row (second half of a prime pair)
@@ -233,15 +232,17 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     const u32 tv = __builtin_amdgcn_sad_u8(pat | (capw & ~PMASK), capw, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // 16 quads (64 disparities) at a time: 5 + 5 ds_read_b128 cover their 17 window dwords in both alignments.
+    // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments
+    // (lane stride CS * 16 bytes: 16 consecutive lanes hit 64 distinct banks for CS = 1 and for CS = 3).
+    const uint4* const win_lds = stage_lds + CS * lane;
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += 16) {
-      constexpr int NM = 5;
+      constexpr int NM = 4;
       uint4 ra[NM], rb[NM];
 #pragma unroll
       for (int m = 0; m < NM; m++) {
-        ra[m] = stage_lds[lane + 16 * (q0 / 4 + m)];
-        rb[m] = stage_lds[lane + 4 + 16 * (q0 / 4 + m)];
+        ra[m] = win_lds[16 * (q0 / 4 + m)];
+        rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
       }
 #pragma unroll
       for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
         u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
 #pragma unroll
         for (int k = 1; k < NTERM; k++) {
-          const uint4 r = xq[(qq / 2) * XS + lane + PW * k];
+          const uint4 r = xq[(qq / 2) * XS + lane + KS * k];
           s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
           s1 += r.y;
           s2 += r.z;
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     if (mine) {
       int tsum = (int)Vt;
 #pragma unroll
-      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + PW * k];
+      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + KS * k];
       bool ok = tsum >= a.tex;
       // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
       if (a.uniq > 0) {
@@ -573,6 +574,49 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
 #endif
 #endif
     }
+  }
+}
+
+// DUAL (windows that are multiples of 3): strips [0, strips3) are column-stride-3 strips in triples, the rest plain ones
+template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, bool DUAL>
+__global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_kernel(FastArgs a) {
+  // XCD-aware decode of the 1-D workgroup id: consecutive ids go round-robin over the 8 XCDs (each with its own
+  // 4 MiB L2), so give XCD k the pairs k, k+8, ...: all strips and row segments of a pair then share one L2.
+  // (Placement only affects speed; any mapping is correct.)
+  // Row segments are the slowest-varying index and get shorter towards the end of the grid: every segment pays w-1
+  // priming rows, so few long segments keep that overhead low while the short last ones keep the tail of the launch
+  // (CUs idling while the last workgroups finish) short.
+  const int bpp = a.strips;                             // workgroups per pair and segment
+  int strip, segi, pair;
+  {
+    const int per_seg = a.strips * a.npairs;
+    segi = blockIdx.x / per_seg;
+    const int b = blockIdx.x - segi * per_seg;
+    const int full = (a.npairs / 8) * 8 * bpp;          // ids covered by complete groups of 8 pairs
+    int p, inner;
+    if (b < full) {
+      const int xcd = b & 7, k = b >> 3;
+      p = (k / bpp) * 8 + xcd;
+      inner = k % bpp;
+    } else {
+      const int r = b - full;
+      p = (a.npairs / 8) * 8 + r / bpp;
+      inner = r % bpp;
+    }
+    pair = p;
+    strip = inner;
+  }
+  if constexpr (DUAL) {
+    constexpr int NV3 = 64 - (NTERM - 1), NV1 = 64 - PW * (NTERM - 1);
+    if (strip < a.strips3) {
+      const int t = strip / 3;
+      sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 3>(a, t * (3 * NV3) + (strip - 3 * t), segi, pair);
+    } else {
+      sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, (a.strips3 / 3) * (3 * NV3) + (strip - a.strips3) * NV1, segi, pair);
+    }
+  } else {
+    constexpr int NV1 = 64 - PW * (NTERM - 1);
+    sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, strip * NV1, segi, pair);
   }
 }
 
@@ -658,19 +702,16 @@ bool sad_fast_supported(const Geom& g) {
 
 template <int NDW, int NWAVES, int NTERM, int PW>
 static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int NCH = (NDW / 4 + 15) / 16;
-  constexpr int NSLOT = ((63 + 4 + 16 * (4 * (NCH - 1) + 4) + 1) + 63) / 64 * 64;
-  constexpr int NQ = NDW / 4, XCH = NQ < 8 ? NQ : 8;
-  constexpr int XS = 64 + PW * (NTERM - 1);
-  constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
-  constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
-  const size_t lds = (size_t)NWAVES * WSLOT * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
-  snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
-           NDW, NWAVES, NTERM, PW, a.nd == NDW * NWAVES ? "true" : "false", a.pfshift);
+  constexpr bool DUAL = PW == 3;
+  constexpr int WSLOT1 = FastLds<NDW, NTERM, PW, 1>::WSLOT, WSLOT3 = FastLds<NDW, NTERM, PW, DUAL ? 3 : 1>::WSLOT;
+  constexpr int WSLOTM = WSLOT1 > WSLOT3 ? WSLOT1 : WSLOT3;
+  const size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
+           NDW, NWAVES, NTERM, PW, a.nd == NDW * NWAVES ? "true" : "false", DUAL ? "true" : "false", a.pfshift);
   if (a.nd == NDW * NWAVES)
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true>), grid, dim3(64 * NWAVES), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true, DUAL>), grid, dim3(64 * NWAVES), lds, s, a);
   else
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, false>), grid, dim3(64 * NWAVES), lds, s, a);
+    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, false, DUAL>), grid, dim3(64 * NWAVES), lds, s, a);
   return hipGetLastError();
 }
 
@@ -713,7 +754,19 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   a.xc0 = g.w2; a.xc1 = xhi - g.w2 + 1;
   const int pw = g.wsz % 3 == 0 ? 3 : 1;
   const int nv = 64 - (g.wsz - pw);
-  const int strips = (a.xc1 - a.xc0 + nv - 1) / nv;
+  // windows that are multiples of 3: triples of column-stride-3 strips (3 * nv3 columns each) as far as they pay, plain
+  // strips for the rest (SBM_FAST_CS3=0: plain strips only)
+  static const int cs3_env = [] { const char* e = getenv("SBM_FAST_CS3"); return e ? atoi(e) : 1; }();
+  const int ncols = a.xc1 - a.xc0;
+  const int nv3 = 64 - (g.wsz / 3 - 1);
+  int triples = 0;
+  if (pw == 3 && cs3_env) {
+    triples = ncols / (3 * nv3);
+    if (ncols - triples * 3 * nv3 > 2 * nv) triples++;   // a remainder worth three plain strips is one more triple
+  }
+  a.strips3 = 3 * triples;
+  const int rem = std::max(0, ncols - triples * 3 * nv3);
+  const int strips = a.strips3 + (rem + nv - 1) / nv;
   const int rows = g.row1 - g.row0;
   // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
   // segment at ~1/3 of a full row's cost) below ~10 %. The target is tuned on the length of the whole SAD stage, interior
@@ -722,7 +775,7 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   // tools/exp/r02_target.sh: 5600 is never worse than 9000 or 4500 on any of the bench workloads)
   int nseg = 1;
   static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 5600L; }();
-  while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 4 * g.wsz) nseg++;
+  while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 3 * g.wsz) nseg++;
   // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
   // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
   while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= g.wsz && nseg < 32) nseg++;
