@@ -40,6 +40,9 @@
 
 // SBM_ABL=n (development builds only, tools/exp/r03_ablate.sh): leave one phase of the row loop out to measure its
 // marginal cost on the GPU; results are wrong by construction.
+#ifndef SBM_FAST_PRIO_XCH   // s_setprio level during the horizontal exchange (0 = off; development builds compare)
+#define SBM_FAST_PRIO_XCH 2
+#endif
 #ifndef SBM_ABL
 #define SBM_ABL 0
 #endif
@@ -304,6 +307,14 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
   for (int y = ys; y < ye; y++) {
     apply(g, 0);
 
+    // Issue priority: the exchange below is a chain of LDS round trips with a few adds behind each; the phases after it are
+    // hundreds of back-to-back vector instructions. With 3-4 wavefronts per SIMD and oldest-first issue, a wavefront in one of
+    // those long arithmetic phases keeps the port while its neighbour's adds wait, the neighbour's next LDS reads go out late
+    // and the CU's LDS pipe idles. Raising the priority of whoever is in the exchange keeps both pipes fed:
+    // KITTI x64 SAD stage 0.963 -> 0.902 ms, 640x480 nd 64 w 21 0.450 -> 0.430, 1080p nd 256 2.59 -> 2.52 (bit-exact, of
+    // course). Also raising it during the mqsad phases gains nothing at nd <= 128 and costs 10 % with cooperating
+    // wavefronts (1080p 2.70 -> 2.96 ms).
+    __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
     // ---- horizontal window across lanes ------------------------------------------------------------------
     // S(c + w/2) = sum_k V(c + 3k): every lane publishes its V quads to LDS ([quad][lane], 8-byte entries: both
     // ds_write_b64 and the shifted ds_read_b64 are conflict-free) and reads the NTERM-1 shifted copies back.
@@ -354,6 +365,7 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
         if (d0 + 2 * j >= a.nd) S[j] = 0xffffffffu;
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- WTA: first index attaining the minimum ------------------------------------------------------------
     // keys carry a group-local index 0..63 (inline constants for v_lshl_or_b32 / v_and_or_b32); the group base is
     // added once per group.  Four independent v_min3_u32 chains per group keep the dependency chains short.
