@@ -282,6 +282,8 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
     for (int k = 0; k < NPH; k++) {
       // ---- SAD: prefix sums over the lanes, window = P[l + 2*hwsz] - P[l - 1] (bm_calc_sad.v:569-605) ---------------
       u32 S[FP_NR];
+      // (issue priority up while the prefix rows go through LDS, as in the interior kernel of the cv flavour: 1 % here)
+      __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int q = 0; q < FP_NR; q++) {
         u32 p = V[k][q];
@@ -297,6 +299,7 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < FP_NR; q++) S[q] = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz] - xrow[q * FP_XS + lane];
+      __builtin_amdgcn_s_setprio(0);
 
       if (sample) {
         // ---- bm_calc_det.v: first minimum of every quarter by keys (value << 16 | idx, idx = lane - 1); reg q holds
