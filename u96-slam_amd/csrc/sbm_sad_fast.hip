@@ -140,7 +140,10 @@ struct FastLds {
   static constexpr int NSLOT = ((CS * 63 + 4 + 16 * (4 * (NCH - 1) + 3) + 1) + 63) / 64 * 64;
   static constexpr int KS = CS == 3 ? 1 : PW;  // lane distance between two partners of the horizontal window
   // horizontal exchange: XCH quads at a time, XS entries per quad pair (64 lanes + the KS*(NTERM-1) halo)
-  static constexpr int XCH = NQ < 8 ? NQ : 8;
+  // (chunk size re-measured once the exchange had its issue priority: 8 quads per chunk -> 4: 1080p -2 %, 2160p -2 %, KITTI
+  // -0.5 %; 2 quads: KITTI -1 % but +4 % / +8 % with cooperating wavefronts -- so 2 where one wavefront holds 128 disparities)
+  static constexpr int XCHMAX = NDW >= 128 ? 2 : 4;
+  static constexpr int XCH = NQ < XCHMAX ? NQ : XCHMAX;
   static constexpr int XS = 64 + KS * (NTERM - 1);
   static constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
   static constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
