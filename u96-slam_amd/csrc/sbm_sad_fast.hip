@@ -501,7 +501,12 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
     // S is dead from here on: fetch the leaving row now (its latency hides behind the rest of the tree, the
     // merge, the sub-pixel arithmetic and the stores) without raising the register peak of the S-heavy phase
 #if SBM_ABL != 5
+    // (the two fetches of a row are issued at raised priority as well, so that a wavefront's loads do not wait behind a
+    // neighbour's arithmetic: KITTI x64 -1 %; with cooperating wavefronts it costs 18 % -- 1080p 2.63 -> 3.10 ms -- hence the
+    // condition)
+    if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
     RowRegs lv = fetch(y - W2);
+    if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(0);
 #endif
 #if SBM_ABL != 1
     {
@@ -579,7 +584,9 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
 #endif
 
     if (y + 1 < ye) {
+      if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
       g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
+      if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(0);
 #if SBM_ABL != 5
       apply(lv, 1);
 #else
