@@ -55,17 +55,57 @@ def usable_cores():
     return n
 
 
-def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start one child process per GPU (this process never touches the
-    GPU, so nothing is exec'ed or forked after HIP initialisation), pass rank 0's JSON line through, fail if any rank
-    fails. Equivalent to `python -m torch.distributed.run --nproc-per-node N bench.py ...`, which still works."""
+def free_port():
     import socket
-    import subprocess
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def run_sg_child(rank, local_rank, world, port, argv, timeout_s):
+    """The chunked RCCL scatter/gather leg in a FRESH child process of this rank (the children of all ranks form their own
+    process group on `port`). The parent only waits: whatever the child does -- hang in a point-to-point batch, crash, never
+    start -- costs at most `timeout_s` and can never touch the measurement the parent already holds. Returns rank 0's
+    scatter_gather dictionary, or {"error": ...}."""
+    import subprocess
+
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(pathlib.Path(__file__).resolve())] + argv + ["--sg-child"]
+    t0 = time.perf_counter()
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, text=True)
+    except OSError as e:
+        return {"error": f"could not start the scatter/gather child: {e}"}
+    try:
+        out, _ = child.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        child.kill()          # exactly the process this rank started
+        child.communicate()
+        return {"error": f"timeout: the scatter/gather child of rank {rank} did not finish within {timeout_s:.0f} s and was killed"}
+    if child.returncode != 0:
+        return {"error": f"the scatter/gather child of rank {rank} exited with status {child.returncode}"}
+    if rank != 0:
+        return None
+    lines = [l for l in (out or "").splitlines() if l.startswith("{")]
+    if not lines:
+        return {"error": "the scatter/gather child of rank 0 printed no result"}
+    sg = json.loads(lines[-1])
+    sg["wall_s_incl_start_up"] = round(time.perf_counter() - t0, 2)
+    return sg
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one child process per GPU (this process never touches the
+    GPU, so nothing is exec'ed or forked after HIP initialisation), pass rank 0's JSON line through, fail if any rank
+    fails. Equivalent to `python -m torch.distributed.run --nproc-per-node N bench.py ...`, which still works."""
+    import subprocess
+
+    port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
@@ -126,6 +166,11 @@ def main():
     ap.add_argument("--feed", choices=("resident", "host"), default="resident",
                     help="host: every rank streams its own shard from PINNED host memory through the engine's chunked three-stream "
                          "host entry point (sbm_compute_batch), inputs and maps crossing PCIe inside the timed region")
+    ap.add_argument("--prewarm-s", type=float, default=0.3,
+                    help="untimed steps for at least this many seconds BEFORE the --warmup steps (clock ramp; disclosed as prewarm_s)")
+    ap.add_argument("--no-sg", action="store_true", help="N>1: skip the scatter/gather leg")
+    ap.add_argument("--sg-timeout", type=float, default=180.0, help="N>1: wall-clock limit of the scatter/gather child processes")
+    ap.add_argument("--sg-child", action="store_true", help=argparse.SUPPRESS)   # internal: this process IS a scatter/gather child
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -249,6 +294,75 @@ def main():
         else:
             bm.launch_raw(B, pl, pr, W, H, pd)
 
+    # ---- the scatter/gather leg (runs in child processes of the timed ranks, see run_sg_child) --------------------------
+    def sg_leg():
+        from u96_slam_amd import shard
+
+        fault = os.environ.get("SBM_BENCH_SG_FAULT", "")      # tests: "hang" / "crash" on the last rank
+        if fault and rank == world - 1:
+            if fault == "hang":
+                time.sleep(3600)
+            os._exit(7)
+        nsg = max(1, min(args.steps, 10))
+        sL = sR = sD = None
+        if rank == 0:
+            parts = [synth.make_batch(r * B, uniq, W, H, nd) for r in range(world)]
+            sL = torch.from_numpy(np.concatenate([np.concatenate([pp[0]] * reps)[:B] for pp in parts])).to(xdev)
+            sR = torch.from_numpy(np.concatenate([np.concatenate([pp[1]] * reps)[:B] for pp in parts])).to(xdev)
+            sD = torch.empty((world * B, H, W), dtype=torch.int16, device=xdev)
+
+        def sg_step():
+            shard.compute_sharded_chunked(compute_chunk, sL, sR, world * B, (H, W), chunk=args.chunk, src=0, device=xdev, out=sD)
+
+        sg_step()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(nsg):
+            sg_step()
+        sync_all()
+        tsg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tsg, op=dist.ReduceOp.MAX)
+        sg_ms = float(tsg.item()) / nsg * 1e3
+        # the same chunks computed back to back without any transfer: what the scatter/gather adds is sg_ms - that
+        t1 = time.perf_counter()
+        for _ in range(nsg):
+            for c0 in range(0, B, args.chunk):
+                bm.compute_device(dL[c0:c0 + args.chunk], dR[c0:c0 + args.chunk], sync=True)
+        tcc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tcc, op=dist.ReduceOp.MAX)
+        chunk_ms = float(tcc.item()) / nsg * 1e3
+        in_bytes, out_bytes = 2.0 * (world - 1) * B * W * H, 2.0 * (world - 1) * B * W * H
+        return {"ms_per_step": round(sg_ms, 4), "value": round(world * B * W * H * nd / (sg_ms * 1e-3) / 1e6, 2),
+                "unit": "Mpix-disparities/s", "steps": nsg, "chunk": args.chunk, "backend": "RCCL" if backend == "nccl" else backend,
+                "compute_only_ms_per_step": round(chunk_ms, 4),
+                "root_link_GBps": round((in_bytes + out_bytes) / (sg_ms * 1e-3) / 1e9, 2),
+                "overlap_frac": round(max(0.0, min(1.0, chunk_ms / sg_ms)), 4) if sg_ms > 0 else None,
+                "note": "measured in fresh child processes of the timed ranks (own process group, wall-clock limit): global batch "
+                        "resident on rank 0, chunked double-buffered point-to-point scatter of the pairs + gather of the maps inside "
+                        "the timed region; overlap_frac = per-rank chunked compute time / scatter-gather step time (1.0 = the "
+                        "transfers are completely hidden under the computation)"}
+
+    if args.sg_child:
+        if dist is None:
+            sys.exit("--sg-child is internal to bench.py --gpus N")
+        res = sg_leg()
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # untimed: a time-based pre-warm (the clocks need some hundred milliseconds of load to settle; --warmup 5 is 5 ms), then
+    # the --warmup steps the command line asks for
+    prewarm_steps = 0
+    if args.prewarm_s > 0 and not scatter:      # (a scattered step holds collectives: every rank must run the same number)
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < args.prewarm_s:
+            for _ in range(8):
+                step()
+            prewarm_steps += 8
+            bm.synchronize()
+            feed_out[0] = 0
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         step()
     sync_all()
@@ -257,9 +371,19 @@ def main():
     # event records cost ~25 us per step: sampling keeps the timed rate within ~0.5 % of the un-instrumented one)
     bm.set_profiling(0 if (args.no_profile or host_feed) else (3 if args.steps >= 8 else 2))
     sync_all()
+    # two event records on the engine's stream bracket the first five timed steps (clock ramp made visible, not hidden)
+    first5 = None
+    mark5 = not scatter and not host_feed and args.steps > 5
+    if mark5:
+        es5 = torch.cuda.ExternalStream(bm.stream(), device=dev)
+        ev5 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t0 = time.perf_counter()
     gathered = None
-    for _ in range(args.steps):
+    if mark5:
+        ev5[0].record(es5)
+    for istep in range(args.steps):
+        if mark5 and istep == 5:
+            ev5[1].record(es5)
         step()
         if args.gather and dist is not None and not scatter:
             from u96_slam_amd import shard
@@ -267,6 +391,8 @@ def main():
             bm.synchronize()
             src = dD if backend == "nccl" else dD.cpu()
             gathered = shard.gather_disparities(src, world * B, dst=0)
+    if mark5:
+        ev5[2].record(es5)
     bm.synchronize()
     feed_out[0] = 0
     torch.cuda.synchronize(dev)
@@ -274,6 +400,8 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    if mark5:
+        first5 = (ev5[0].elapsed_time(ev5[1]) / 5.0, ev5[1].elapsed_time(ev5[2]) / (args.steps - 5))
     prof = bm.profile()
     bm.set_profiling(0)
     if dist is not None:
@@ -321,45 +449,13 @@ def main():
         dist.all_gather_object(idents, (rank, local_rank, ident))
         rccl = {"backend": backend, "ranks_seen": len(idents), "distinct_devices": len({i[2] for i in idents}),
                 "devices": [i[2] for i in idents]}
-        if not scatter and not host_feed:
-            from u96_slam_amd import shard
-
-            nsg = max(1, min(args.steps, 10))
-            if rank == 0:
-                parts = [synth.make_batch(r * B, uniq, W, H, nd) for r in range(world)]
-                gL = torch.from_numpy(np.concatenate([np.concatenate([pp[0]] * reps)[:B] for pp in parts])).to(xdev)
-                gR = torch.from_numpy(np.concatenate([np.concatenate([pp[1]] * reps)[:B] for pp in parts])).to(xdev)
-                gD = torch.empty((world * B, H, W), dtype=torch.int16, device=xdev)
-
-            def sg_step():
-                shard.compute_sharded_chunked(compute_chunk, gL, gR, world * B, (H, W), chunk=args.chunk, src=0, device=xdev, out=gD)
-
-            sg_step()
-            sync_all()
-            t1 = time.perf_counter()
-            for _ in range(nsg):
-                sg_step()
-            sync_all()
-            tsg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(tsg, op=dist.ReduceOp.MAX)
-            sg_ms = float(tsg.item()) / nsg * 1e3
-            # the same chunks computed back to back without any transfer: what the scatter/gather adds is sg_ms - that
-            t1 = time.perf_counter()
-            for _ in range(nsg):
-                for c0 in range(0, B, args.chunk):
-                    bm.compute_device(dL[c0:c0 + args.chunk], dR[c0:c0 + args.chunk], sync=True)
-            tcc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(tcc, op=dist.ReduceOp.MAX)
-            chunk_ms = float(tcc.item()) / nsg * 1e3
-            in_bytes, out_bytes = 2.0 * (world - 1) * B * W * H, 2.0 * (world - 1) * B * W * H
-            sg = {"ms_per_step": round(sg_ms, 4), "value": round(world * B * W * H * nd / (sg_ms * 1e-3) / 1e6, 2),
-                  "unit": "Mpix-disparities/s", "steps": nsg, "chunk": args.chunk, "backend": "RCCL" if backend == "nccl" else backend,
-                  "compute_only_ms_per_step": round(chunk_ms, 4),
-                  "root_link_GBps": round((in_bytes + out_bytes) / (sg_ms * 1e-3) / 1e9, 2),
-                  "overlap_frac": round(max(0.0, min(1.0, chunk_ms / sg_ms)), 4) if sg_ms > 0 else None,
-                  "note": "global batch resident on rank 0, chunked double-buffered point-to-point scatter of the pairs + gather of the "
-                          "maps inside the timed region; overlap_frac = per-rank chunked compute time / scatter-gather step time "
-                          "(1.0 = the transfers are completely hidden under the computation)"}
+        if not scatter and not host_feed and not args.no_sg:
+            # the point-to-point leg runs in fresh child processes with a wall-clock limit: a hang or fault in there costs
+            # sg_timeout seconds and an error field, never the measurement above
+            port = [free_port() if rank == 0 else None]
+            dist.broadcast_object_list(port, src=0)
+            dist.barrier()
+            sg = run_sg_child(rank, int(os.environ.get("LOCAL_RANK", "0")), world, port[0], sys.argv[1:], args.sg_timeout)
 
     # ---- host feed: the three legs on their own (resident compute, H2D of the inputs, D2H of the maps) -> how much of the
     # shorter legs the three-stream pipeline hides: overlap_frac = 1 when a step costs only its slowest leg, 0 when the sum
@@ -534,11 +630,15 @@ def main():
                            else "disparity maps gathered on rank 0 each step" if (args.gather and world > 1)
                            else "every rank streams its shard from pinned host memory (PCIe inside the timed region)" if host_feed
                            else "shards resident, no data-path collective (value); scatter_gather = the chunked RCCL scatter/gather from rank 0")},
+            "prewarm_s": args.prewarm_s, "prewarm_steps": prewarm_steps,
+            "ms_per_step_first5": round(first5[0], 4) if first5 else None,
+            "ms_per_step_after5": round(first5[1], 4) if first5 else None,
             "ms_per_step_median": round(step_ms[len(step_ms) // 2], 4) if step_ms else None,
             "ms_per_step_min": round(step_ms[0], 4) if step_ms else None,
             "ms_per_pair": round(elapsed / (B * args.steps) * 1e3, 5),
             "pairs_per_s": round(total_pairs / elapsed, 1),
             "roofline": roofline, "roofline_prefilter": roofline_pf, "cpu_baseline": cpu,
+            "engine_library": pkg.stereobm.loaded_library_name(),
         }
         if step_ms:
             out["ms_per_step_from"] = (f"{len(step_ms)} further steps, " + ("host wall clock per sbm_compute_batch call" if host_feed else "one HIP event per step on the engine's stream"))
@@ -557,10 +657,9 @@ def main():
                                         "step; overlap_frac = 1 when a step costs only its slowest leg (measured alone: resident_compute_ms, h2d_ms, "
                                         "d2h_ms), 0 when it costs their sum; sync_call_ms_per_step = the same batch through one synchronous "
                                         "sbm_compute_batch call per step (chunked pipeline inside the call)"}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()     # (no barrier: the ranks have nothing left to agree on)
 
 
 if __name__ == "__main__":

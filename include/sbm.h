@@ -21,6 +21,32 @@
  *
  * There is NO CPU backend behind this ABI: if no HIP device is usable sbm_create() fails with
  * SBM_ERR_NO_DEVICE. The CPU restatement used by the tests lives in oracle/ and is never linked here.
+ *
+ * Exactness. Every parameter set cv::StereoBM accepts is computed (block sizes 5..255, any multiple of 16 disparities, any
+ * minDisparity / ROI); sets inside the fast envelope -- odd block size 5..27, numDisparities <= 256, blockSize^2 * 2 *
+ * preFilterCap <= 65534 -- run the hand-tuned kernels, everything else a generic kernel (~50x slower, same results).
+ * Bit-exactness against cv::StereoBM is CLAIMED for blockSize^2 * 2 * preFilterCap <= 32767 only (the reference's 21 x 21
+ * at cap 31 is 27 342): OpenCV keeps its block-matching cost plane as `short`, so beyond that bound its left-right check
+ * would see a wrapped cost where this engine (and its oracle) keep the true one.
+ *
+ * Environment. The library reads these variables (nothing else); an integrator never needs to set any of them:
+ *   variable            default  read      who sets it, and what for
+ *   SBM_FAST_INPLACE    1        once      0 = run the two-accumulator build of the SAD kernel (the fallback that is taken
+ *                                          automatically when the device self-test of the in-place v_mqsad accumulate
+ *                                          fails); set by the GPU tests to check that fallback
+ *   SBM_FAST_MODE       1        once      0 = 64 disparities per wavefront (round-2 layout), 2 = two 128-disparity wavefronts
+ *                                          beyond 192 disparities; GPU tests / A-B measurements
+ *   SBM_FAST_PFSHIFT    2        once      0 = unscaled prefiltered planes (plain winner search), 1 = at most one tag bit;
+ *                                          GPU tests
+ *   SBM_FAST_CS3        1        per call  0 = plain column strips only (no column-stride-3 strips); GPU tests
+ *   SBM_SPECKLE_LISTS   1        per call  0 = row-walking count / apply kernels of the speckle filter; GPU tests
+ *   SBM_SPECKLE_BAND    auto     per call  0 / 2 / 4 / 8 = band height of the speckle filter's band walk (0: round-1 kernels);
+ *                                          GPU tests
+ * Tuning knobs of the measurement scripts (SBM_FAST_TARGET, SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
+ * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*) exist only in development builds (-DSBM_DEV,
+ * tools/exp/r04_devlib.sh); this library ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this
+ * library inside u96-slam_amd/lib/, A-B measurements only); bench.py reads SBM_BENCH_BACKEND / SBM_BENCH_FEED /
+ * SBM_BENCH_SG_FAULT (tests of its multi-process control flow).
  */
 #ifndef SBM_H_
 #define SBM_H_
@@ -116,12 +142,11 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
  * other stream of the caller. The inputs must be complete before the call (synchronise the producing stream, or make
  * sbm_stream() wait on an event of the producer with hipStreamWaitEvent), and with sync == 0 the buffers must stay
  * alive and untouched until sbm_synchronize() or an event recorded on sbm_stream() after the call has completed.
- * Internally the call forks helper streams (the border-column kernel runs underneath the interior SAD kernel);
- * everything is joined back into the handle's stream before the call's work counts as finished. */
+ * Every kernel of the call runs on the handle's stream (one SAD launch: the clamped border columns are extra wavefronts
+ * of it). */
 int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, int width, int height,
                        void* d_disp, int sync);
 
-/* Block until everything queued on the handle's stream has finished. */
 /* Asynchronous dense feed (what a per-GPU feeder thread of a multi-GPU job uses; bench.py --feed host): sbm_submit_dense
  * queues one dense batch -- left/right: n*height*width bytes each, disp: n*height*width int16, all in HOST memory that
  * should be pinned -- and returns at once; at most three submissions are in flight (a fourth call first waits for the oldest).
@@ -133,6 +158,8 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
 int sbm_submit_dense(sbm_handle* h, int n, const uint8_t* left, const uint8_t* right, int width, int height, int16_t* disp);
 int sbm_wait_oldest(sbm_handle* h);
 
+/* Block until everything queued on the handle's stream has finished and every outstanding submission of the asynchronous
+ * feed has delivered its maps. */
 int sbm_synchronize(sbm_handle* h);
 
 /* Intermediate planes of the LAST sbm_compute_device call, for stage-by-stage parity tests.

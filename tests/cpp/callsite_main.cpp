@@ -1,8 +1,10 @@
 // The reference's call site (src/slam/src/core/main.cpp:197-217) with the one-line type swap of INTEGRATION.md:
 // a matcher is created INSIDE the frame loop (main.cpp:201), configured with the 11 setters (main.cpp:202-212) and
 // asked for one disparity map (main.cpp:215). Frames come from raw 8-bit files instead of cv::imread so that the
-// program builds without OpenCV; with OpenCV headers present the cv::InputArray overload is exercised as well
-// (compile with -DSBM_TEST_WITH_OPENCV).
+// program builds without OpenCV; with OpenCV headers present -- the real ones, or the mock of the few names involved
+// under tests/cpp/mock_opencv, which pins nothing about OpenCV's arithmetic -- the cv::InputArray / cv::OutputArray
+// overload is what computes (compile with -DSBM_TEST_WITH_OPENCV): plain cv::Mat destination, a fixed CV_32F destination
+// and the error -> cv::Exception mapping.
 //
 //   callsite_main <width> <height> <nframes> <left.raw> <right.raw> <disp_out.raw>
 //
@@ -49,6 +51,16 @@ int main(int argc, char** argv) {
       bm->compute(l, r, d);
       if (d.type() != CV_16SC1 || d.rows != H || d.cols != W) return 5;
       for (int y = 0; y < H; y++) std::copy(d.ptr<int16_t>(y), d.ptr<int16_t>(y) + W, disp.data() + i * npix + (size_t)y * W);
+      if (i == 0) {
+        // a destination with a fixed CV_32F type receives disparity / 16 as float (what SensorData::setImageDepth and
+        // Stereo.cpp:79-83 of the reference would read)
+        cv::Mat_<float> df;
+        bm->compute(l, r, df);
+        if (df.type() != CV_32FC1 || df.rows != H || df.cols != W) return 7;
+        for (int y = 0; y < H; y++)
+          for (int x = 0; x < W; x++)
+            if (df.ptr<float>(y)[x] != (float)d.ptr<int16_t>(y)[x] / 16.f) return 8;
+      }
 #else
       bm->compute(left.data() + i * npix, (size_t)W, right.data() + i * npix, (size_t)W, W, H, disp.data() + i * npix,
                   (size_t)W * sizeof(int16_t));
@@ -66,6 +78,24 @@ int main(int argc, char** argv) {
     catch (const cv::Exception&) { threw = true; }
 #endif
     if (!threw) return 6;
+#ifdef SBM_TEST_WITH_OPENCV
+    // the same through the cv::Mat overload: a cv::Exception, as cv::StereoBM::compute's CV_Error raises
+    {
+      cv::Mat l(H, W, CV_8UC1, left.data()), r(H, W, CV_8UC1, right.data()), d;
+      bool cvthrew = false;
+      try {
+        bad->compute(l, r, d);
+      } catch (const cv::Exception&) { cvthrew = true; }
+      if (!cvthrew) return 9;
+      // images of different sizes / of the wrong type are refused before anything reaches the engine
+      cv::Mat small(H - 1, W, CV_8UC1, right.data());
+      cvthrew = false;
+      try {
+        sbm::StereoBM::create(16, 9)->compute(l, small, d);
+      } catch (const cv::Exception&) { cvthrew = true; }
+      if (!cvthrew) return 10;
+    }
+#endif
   } catch (const std::exception& e) {
     std::fprintf(stderr, "callsite_main: %s\n", e.what());
     return 4;

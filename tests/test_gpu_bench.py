@@ -57,6 +57,53 @@ def test_two_ranks_self_launched(extra):
         assert j["ms_per_step_median"] >= j["ms_per_step_min"] > 0
 
 
+@pytest.mark.parametrize("fault", ["hang", "crash"])
+def test_scatter_gather_fault_cannot_lose_the_value(fault):
+    """The point-to-point leg runs in child processes of the timed ranks with a wall-clock limit: a rank that hangs (or dies)
+    in there costs the timeout and an error field -- rc 0, one JSON line and the shards-resident value survive."""
+    j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "8", "--no-cpu-baseline", "--sg-timeout", "40"],
+             env={"SBM_BENCH_BACKEND": "gloo", "SBM_BENCH_SG_FAULT": fault})
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["rccl"]["ranks_seen"] == 2
+    assert "error" in j["scatter_gather"] and ("timeout" in j["scatter_gather"]["error"] or "exited" in j["scatter_gather"]["error"])
+
+
+def test_first_steps_and_prewarm_are_disclosed():
+    j = _run(["--steps", "12", "--warmup", "2", "--pairs", "8", "--no-cpu-baseline"])
+    assert j["prewarm_s"] == 0.3 and j["prewarm_steps"] >= 8 and j["warmup"] == 2 and j["steps"] == 12
+    assert j["ms_per_step_first5"] > 0 and j["ms_per_step_after5"] > 0 and j["engine_library"] == "libsbm_hip.so"
+
+
+def test_host_submissions_do_not_pile_up():
+    """A feeder that never calls synchronize(): wait_host() hands every delivered batch back."""
+    import numpy as np
+
+    sys.path.insert(0, str(ROOT))
+    import _pkg
+
+    pkg = _pkg.load()
+    from u96_slam_amd import synth
+
+    W, H, nd, B = 160, 48, 32, 2
+    bm = pkg.StereoBM.create(nd, 9, device=0)
+    L, R = synth.make_batch(0, B, W, H, nd)
+    ref = bm.compute(L, R)
+    outs = []
+    for k in range(100):
+        out = np.empty((B, H, W), np.int16)
+        bm.submit_host(L, R, out)
+        outs.append(out)
+        if k >= 2:
+            bm.wait_host()
+            assert np.array_equal(outs[k - 2], ref)
+        assert len(bm._host_inflight) <= 3
+    # a synchronous host call between submissions and their waits must not disturb the queue (ADVICE r03, medium):
+    # it re-sizes its own staging only
+    big = synth.make_batch(5, 3, W + 16, H + 8, nd)
+    bm.compute(big[0], big[1])
+    bm.wait_host(); bm.wait_host()
+    assert np.array_equal(outs[98], ref) and np.array_equal(outs[99], ref) and len(bm._host_inflight) == 0
+
+
 def test_async_dense_feed_matches_the_synchronous_call():
     """sbm_submit_dense / sbm_wait_oldest: three batches in flight on two device staging sets, results identical to
     sbm_compute_batch and to the oracle, buffers of different submissions never mix."""

@@ -2,7 +2,7 @@
 // kernel orchestration.  Replaces cv::StereoBM::compute at src/slam/src/core/main.cpp:201-216.
 //
 // Stage order (same as cv::StereoBM::compute): prefilter both images -> SAD/WTA on the valid-ROI rows
-// (fast kernel on interior columns, generic kernel on the clamped border columns) -> LR check + invalid
+// (fast kernel: interior columns + the clamped border columns as extra wavefronts of the same launch; generic kernel otherwise) -> LR check + invalid
 // row/column fill -> speckle filter.  Everything is enqueued on the handle's stream; no host sync inside.
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,8 +21,6 @@ struct sbm_handle {
   sbm_params p;
   int device;
   hipStream_t stream;
-  hipStream_t stream2;   // side stream: the latency-bound border kernel overlaps the VALU-bound SAD kernel
-  hipEvent_t ev_fork, ev_join;
   int last_hip;
   // scratch, sized for (cap_n, cap_W, cap_H, cap pitch)
   int cap_n, cap_W, cap_H, cap_pitch;
@@ -170,10 +168,16 @@ static void free_fpga(sbm_handle* h) {
   h->fp_n = h->fp_W = h->fp_H = 0;
 }
 
-static void free_staging(sbm_handle* h) {
-  hipFree(h->st_l); hipFree(h->st_r); hipFree(h->st_d);
+// The device sets of the asynchronous dense feed have their own life: submissions may be outstanding (the newest one's
+// trip home not even queued yet) while a synchronous host entry point resizes ITS staging, so only the feed's own realloc
+// path (drained first) and the handle's end of life free them.
+static void free_feed(sbm_handle* h) {
   for (int k = 0; k < 2; k++) { hipFree(h->fq_l[k]); hipFree(h->fq_r[k]); hipFree(h->fq_d[k]); h->fq_l[k] = h->fq_r[k] = nullptr; h->fq_d[k] = nullptr; }
   h->fq_n = h->fq_W = h->fq_H = 0;
+}
+
+static void free_staging(sbm_handle* h) {
+  hipFree(h->st_l); hipFree(h->st_r); hipFree(h->st_d);
   if (h->pin) hipHostFree(h->pin);
   h->pin = nullptr; h->pin_bytes = 0;
   h->st_l = h->st_r = nullptr; h->st_d = nullptr; h->st_n = h->st_W = h->st_H = 0;
@@ -195,6 +199,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   if (h->labels) b += npix * 14 + (size_t)h->cap_n * h->cap_H * 6;   // labels, counts, head lists, seam lists
   if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
+  b += (size_t)h->fq_n * h->fq_W * h->fq_H * 8;
   b += (size_t)h->fp_n * h->fp_W * h->fp_H * 10;
   return b;
 }
@@ -240,11 +245,6 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
   }
   // every failure below goes through destroy_now(), which tolerates the members that were never created (null)
   bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
-  int lo = 0, hi = 0;
-  ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
-  ok = ok && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     destroy_now(h);
     return SBM_ERR_HIP;
@@ -258,7 +258,6 @@ int sbm_create(sbm_handle** out, const sbm_params* p, int device) {
 
 static void sync_all_streams(sbm_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
-  if (h->stream2) hipStreamSynchronize(h->stream2);
   if (h->stream_in) hipStreamSynchronize(h->stream_in);
   if (h->stream_out) hipStreamSynchronize(h->stream_out);
 }
@@ -267,6 +266,12 @@ void sbm_destroy(sbm_handle* h) {
   if (!h) return;
   DeviceScope dscope(h->device);
   dscope.enter();
+  // submissions of the asynchronous feed nobody waited for: deliver their maps (the newest one's trip home is only queued by
+  // a wait), then forget the queue whatever happened
+  while (h->fq_waited != h->fq_submitted)
+    if (sbm_wait_oldest(h) != SBM_OK) break;
+  h->fq_waited = h->fq_submitted;
+  h->fq_pending_dst = nullptr;
   sync_all_streams(h);
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -274,6 +279,7 @@ void sbm_destroy(sbm_handle* h) {
       if (scratch_bytes(h) > kPoolScratch) {
         free_scratch(h);
         free_staging(h);
+        free_feed(h);
         free_fpga(h);
       }
       g_pool[g_pool_n++] = h;
@@ -291,6 +297,7 @@ static void destroy_now(sbm_handle* h) {
   sync_all_streams(h);
   free_scratch(h);
   free_staging(h);
+  free_feed(h);
   free_fpga(h);
   for (int r = 0; r < sbm_handle::kRing; r++)
     for (int i = 0; i < sbm_handle::kMarks; i++)
@@ -306,9 +313,6 @@ static void destroy_now(sbm_handle* h) {
   }
   if (h->stream_in) hipStreamDestroy(h->stream_in);
   if (h->stream_out) hipStreamDestroy(h->stream_out);
-  if (h->ev_fork) hipEventDestroy(h->ev_fork);
-  if (h->ev_join) hipEventDestroy(h->ev_join);
-  if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -477,7 +481,8 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   // columns left and right of the fast range: clamped windows. They only matter if they can influence the output:
   // through the LR check or when inside the valid ROI.
   const bool borders_visible = g.want_cost || g.col0 < g.lofs + fa || g.col1 > g.lofs + fb;
-  const bool side = fast && borders_visible;   // border columns on the side stream, under the interior kernel
+  // ... and then they ride in the interior launch as extra wavefronts (sbm_sad_border_wave.h): one SAD launch, one stream
+  const bool border = fast && borders_visible;
   // Stages run one after the other on the main stream. Overlapping LR + speckle of one sub-batch with the SAD kernel of
   // the next was built and measured in round 2 (profiles/r02_subbatch_pipeline.md; the code is in the history at commit
   // "Engine: device guard ..."): 1.47 ms -> 1.54 / 1.73 ms with 2 / 4 sub-batches, because four 126-VGPR wavefronts per
@@ -498,22 +503,15 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   }
   mark(h, 1);
   if (any_rows) {
-    if (side) {
-      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      HIPCHK(h, launch_sad_border(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, fa, fb, h->stream2));
-      HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
-    }
     if (fast) {
       int xa = 0, xb = 0;
-      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, h->stream));
+      HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, border, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", g_sad_kernel_name);
     } else {
       HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_generic_kernel");
     }
     mark(h, 2);
-    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
   } else {
     mark(h, 2);
   }
@@ -877,7 +875,7 @@ static int pipelined_enqueue(sbm_handle* h, int n, const uint8_t* const* left, c
   // 0.36 ms on the device, 64 pairs 1.2 ms), so: a small FIRST chunk (the computation starts after one short transfer), a
   // small LAST one (only its computation and its maps are left when the inputs have arrived) and large ones in between.
   // Measured on 64 KITTI pairs from pinned memory (profiles/r03_host_feed.json). SBM_HOST_CHUNK=<pairs>: uniform chunks.
-  static const int chunk_env = [] { const char* e = getenv("SBM_HOST_CHUNK"); return e ? atoi(e) : 0; }();
+  static const int chunk_env = SBM_TUNE("SBM_HOST_CHUNK", 0);
   int start[sbm_handle::kChunks + 1];
   int nch = 0;
   start[0] = 0;
@@ -1000,11 +998,7 @@ int sbm_submit_dense(sbm_handle* h, int n, const uint8_t* left, const uint8_t* r
       if (st != SBM_OK) return st;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int k = 0; k < 2; k++) {
-      hipFree(h->fq_l[k]); hipFree(h->fq_r[k]); hipFree(h->fq_d[k]);
-      h->fq_l[k] = h->fq_r[k] = nullptr; h->fq_d[k] = nullptr;
-    }
-    h->fq_n = 0;
+    free_feed(h);
     for (int k = 0; k < 2; k++) {
       HIPCHK(h, hipMalloc((void**)&h->fq_l[k], npix + 64));
       HIPCHK(h, hipMalloc((void**)&h->fq_r[k], npix + 64));
@@ -1053,7 +1047,7 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
   // transfer per row (measured 5.6 ms per 1242x375 pair against 0.2 ms packed).
   const bool in_dense = left_stride == (size_t)width && right_stride == (size_t)width;
   const bool out_dense = disp_stride == (size_t)width * 2;
-  static const int pipe_env = [] { const char* e = getenv("SBM_HOST_PIPELINE"); return e ? atoi(e) : 1; }();
+  static const int pipe_env = SBM_TUNE("SBM_HOST_PIPELINE", 1);
   if (in_dense && out_dense && n >= 16 && pipe_env && !h->profiling)
     return compute_batch_pipelined(h, n, left, right, width, height, disp);
   if (!in_dense || !out_dense) {

@@ -5,7 +5,26 @@
 
 #include "../../include/sbm.h"
 
+#include <stdlib.h>
+
 namespace sbm {
+
+// Environment switches of the library -- the complete list, documented for integrators in include/sbm.h ("Environment").
+//   env_switch(): read in every build. They select a tested fallback or a code path that the GPU tests compare with the
+//                 default one: SBM_FAST_INPLACE, SBM_FAST_MODE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS,
+//                 SBM_SPECKLE_BAND.
+//   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_TARGET, SBM_FAST_NSEG, SBM_FAST_TAPER,
+//                 SBM_FAST_UNIQ_PLAIN, SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*): compiled in
+//                 only with -DSBM_DEV (the development library of tools/exp/r04_devlib.sh); the product ignores them.
+inline int env_switch(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#ifdef SBM_DEV
+#define SBM_TUNE(name, dflt) ::sbm::env_switch(name, dflt)
+#else
+#define SBM_TUNE(name, dflt) (dflt)
+#endif
 
 // Geometry of one launch, derived on the host from sbm_params and the image size. Naming follows
 // cv::StereoBM (calib3d stereobm.cpp): lofs/rofs/width1, buffer index d <-> true disparity nd-1-d+mindisp.
@@ -31,8 +50,8 @@ struct Geom {
 // With Geom::pfshift = 2 the planes store 4*value+1 (<= 253): every absolute difference, hence every SAD, is a multiple
 // of 4, which leaves the two low bits of the packed 16-bit sums free for a register tag in the interior kernel's
 // winner search (sbm_sad_fast.hip; chosen by sad_fast_pfshift() when 4*maxS still fits 16 bits; pfshift = 1: 2*value+1,
-// one tag bit, where only 2*maxS fits). The border kernels
-// take the scale out again when they stage a row.
+// one tag bit, where only 2*maxS fits). The border wavefronts of the same launch work on the scaled sums too; only the
+// uniqueness threshold and the stored cost go back to the unscaled sum.
 constexpr int kPfBias = 1;
 
 hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8_t* pf_l, uint8_t* pf_r,
@@ -54,13 +73,10 @@ extern thread_local char g_sad_kernel_name[96];
 bool sad_fast_supported(const Geom& g);
 bool mqsad_inplace_ok(hipStream_t s);   // device self-test behind the in-place v_mqsad accumulate (cached per device)
 int sad_fast_pfshift(const Geom& g);   // 2 or 1 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
+// border: the w/2 clamped columns on each side of [xa,xb) are computed by extra wavefronts of the same launch
+// (sbm_sad_border_wave.h); without it the launch leaves them untouched.
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
-                           int* xa, int* xb, hipStream_t s);
-
-// Border columns next to the fast range: [0,xa) and [xb,xend), w/2 columns each, clamped windows, sliding sums over
-// "virtual columns" (see sbm_sad_border.hip). Same envelope as the fast kernel.
-hipError_t launch_sad_border(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
-                             int xa, int xb, hipStream_t s);
+                           int* xa, int* xb, bool border, hipStream_t s);
 
 // Left-right consistency (cv validateDisparity) + invalid rows/columns fill. Reads disp_pre/cost, writes disp_out.
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
 // Infinity Cache (4.3 vs 4.0 TB/s at 119 MB), 8 rows beyond it (4.4-4.9 vs 4.1-4.5 TB/s at 1.9-2.1 GB, i.e. 98-105 % of
 // the runtime's device-to-device copy of the same bytes). SBM_PF_ROWS=2|4|8 overrides.
 static int pf_rows(size_t bytes_in_out) {
-  static const int env = [] { const char* e = getenv("SBM_PF_ROWS"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 8) ? v : 0; }();
+  static const int env = [] { const int v = SBM_TUNE("SBM_PF_ROWS", 0); return (v == 2 || v == 4 || v == 8) ? v : 0; }();
   if (env) return env;
   return bytes_in_out > ((size_t)256 << 20) ? 8 : 4;
 }

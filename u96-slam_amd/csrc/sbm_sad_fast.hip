@@ -35,16 +35,12 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "sbm_common.h"
 
-// SBM_ABL=n (development builds only, tools/exp/r03_ablate.sh): leave one phase of the row loop out to measure its
-// marginal cost on the GPU; results are wrong by construction.
 #ifndef SBM_FAST_PRIO_XCH   // s_setprio level during the horizontal exchange (0 = off; development builds compare)
 #define SBM_FAST_PRIO_XCH 2
-#endif
-#ifndef SBM_ABL
-#define SBM_ABL 0
 #endif
 #ifndef SBM_FAST_PINGPONG
 #define SBM_FAST_PINGPONG 0
@@ -79,6 +75,11 @@ struct FastArgs {
   int uniq_plain;            // 8 * (maxS * uniq / 100 + 1) fits 16 bits: deficit partial sums need no saturating adds
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
   int pfshift;               // the planes hold (value << pfshift) + 1: every sum below is scaled by 1 << pfshift (0 or 2)
+  // border jobs (sbm_sad_border_wave.h): the grid starts with nbseg x bord workgroups that carry the clamped border columns
+  int bord;                  // border workgroups per border row segment (a multiple of 8; 0: no border columns wanted)
+  int bgx;                   // border wavefronts per XCD residue and segment: 2 sides x pair groups
+  int bpstride;              // pair stride inside a border wavefront (8: its pairs share an XCD with their strips; 1: huge planes)
+  int bseg, nbseg;           // the border jobs' own row segments: nbseg segments of bseg rows (the last one shorter)
 };
 
 __device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t* p) {
@@ -112,6 +113,8 @@ __device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) {
 }
 
 extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NSLOT 16-byte slots, then exchange area
+
+#include "sbm_sad_border_wave.h"
 
 // NDW disparities per wavefront, NWAVES wavefronts per workgroup covering NDW*NWAVES >= nd disparities of the SAME
 // 64 columns.  NWAVES > 1 keeps the register footprint of a wavefront at NDW/2 accumulators + NDW/2 sums (4 waves per
@@ -328,10 +331,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
     const int par = y & 1;
     const int orow = __builtin_amdgcn_readfirstlane(2 * y * a.W);
     xt[lane] = Vt;
-#if SBM_ABL == 4
-#pragma unroll
-    for (int q = 0; q < NQ; q++) { const uint2 v = __builtin_bit_cast(uint2, VB[q]); S[2 * q] = v.x; S[2 * q + 1] = v.y; }
-#else
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += XCH) {
       // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
@@ -361,7 +360,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
       }
       __builtin_amdgcn_wave_barrier();
     }
-#endif
     if constexpr (!EXACT_ND) {
 #pragma unroll
       for (int j = 0; j < NR; j++)
@@ -373,14 +371,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
     // keys carry a group-local index 0..63 (inline constants for v_lshl_or_b32 / v_and_or_b32); the group base is
     // added once per group.  Four independent v_min3_u32 chains per group keep the dependency chains short.
     u32 best = 0xffffffffu;
-#if SBM_ABL == 3
-    {
-      u32 f = 0;
-#pragma unroll
-      for (int j = 0; j < NR; j += 8) f ^= S[j];
-      best = ((f & 0x3fffu) << 16) | ((f >> 16) & 63u);
-    }
-#else
     // (one tagged variant per instantiation, chosen by the window: a third alternative in the same loop body makes the
     // register allocator spill hundreds of bytes in every instantiation)
     constexpr int TSMAX = WSZ <= 15 ? 2 : 1;
@@ -432,7 +422,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
       best = min(best, bg);
     }
     }
-#endif
     best += (u32)d0;
     const int mpar = par * NWAVES * 64;   // the merge arrays alternate by row parity
     if constexpr (NWAVES > 1) {
@@ -458,9 +447,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
       u32 ac[NACC];
 #pragma unroll
       for (int k = 0; k < NACC; k++) ac[k] = 0u;
-#if SBM_ABL == 2
-      ac[0] = S[0] ^ S[NR - 1] ^ T2;
-#else
       if (a.uniq_plain) {
 #pragma unroll
         for (int j = 0; j < NR; j++) ac[j % NACC] += pk_sub_sat(T2, S[j]);
@@ -472,7 +458,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
 #pragma unroll
         for (int j = 0; j < NR; j++) ac[j % NACC] = pk_add_sat(ac[j % NACC], pk_sub_sat(T2s, S[j]));
       }
-#endif
 #pragma unroll
       for (int n = NACC; n > 1; n >>= 1)
 #pragma unroll
@@ -488,27 +473,20 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
     // byte selectors built arithmetically from the packed index pair (compares + selects cost several times as much):
     // low half of every selector follows ln, high half lp
     const u32 lnp = (u32)ln | ((u32)lp << 16);
-#if SBM_ABL == 1
-    X[0] = (S[0] ^ S[NR - 1] ^ lnp) & 0x3fff3fffu;
-#else
     {
       // bytes (2a, 2a+1) with a = index & 3:  0x0100 + a * 0x0202 per half
       const u32 sel = __umul24(lnp & 0x00030003u, 0x0202u) + 0x01000100u;
 #pragma unroll
       for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
     }
-#endif
     // S is dead from here on: fetch the leaving row now (its latency hides behind the rest of the tree, the
     // merge, the sub-pixel arithmetic and the stores) without raising the register peak of the S-heavy phase
-#if SBM_ABL != 5
     // (the two fetches of a row are issued at raised priority as well, so that a wavefront's loads do not wait behind a
     // neighbour's arithmetic: KITTI x64 -1 %; with cooperating wavefronts it costs 18 % -- 1080p 2.63 -> 3.10 ms -- hence the
     // condition)
     if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
     RowRegs lv = fetch(y - W2);
     if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(0);
-#endif
-#if SBM_ABL != 1
     {
       int lvl = 2;
 #pragma unroll
@@ -521,7 +499,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
         lvl++;
       }
     }
-#endif
     int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
     u32 acc_lo = acc & 0xffffu, acc_hi = acc >> 16;
     bool mine = true;  // does this wavefront finalise this row?
@@ -542,9 +519,6 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
       }
     }
 
-#if SBM_ABL == 6
-    if (mine && produces) __builtin_amdgcn_raw_buffer_store_b16((short)(best ^ acc_lo ^ acc_hi ^ (u32)nn ^ (u32)pp), rs_d, ocol, orow, 0);
-#else
     if (mine) {
       int tsum = (int)Vt;
 #pragma unroll
@@ -581,20 +555,12 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
         __builtin_amdgcn_raw_buffer_store_b16((short)out, rs_d, ocol, orow, 0);
       }
     }
-#endif
 
     if (y + 1 < ye) {
       if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
       g = fetch(y + 1 + W2);   // next entering row: latency hides behind the leaving row's mqsad + subtractions
       if constexpr (NWAVES == 1) __builtin_amdgcn_s_setprio(0);
-#if SBM_ABL != 5
       apply(lv, 1);
-#else
-#if SBM_FAST_PINGPONG
-#pragma unroll
-      for (int q = 0; q < NQ; q++) VA[q] = __builtin_bit_cast(uint2, VB[q]);
-#endif
-#endif
     }
   }
 }
@@ -611,9 +577,21 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
   const int bpp = a.strips;                             // workgroups per pair and segment
   int strip, segi, pair;
   {
+    // The grid starts with the border jobs (a.bord workgroups for each of their a.nbseg row segments, sbm_sad_border_wave.h):
+    // they are long serial chains, so they are dispatched before any strip and finish under the strips instead of behind them.
+    if ((int)blockIdx.x < a.bord * a.nbseg) {
+      // wavefront wv of border workgroup b takes border wavefront (b >> 3) * NWAVES + wv of XCD residue b & 7; no barriers in there
+      using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
+      const int bseg = blockIdx.x / a.bord, b = blockIdx.x - bseg * a.bord;
+      const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+      const int gi = (b >> 3) * NWAVES + wv;
+      if (gi < a.bgx) sad_border_wave<(PW * NTERM) / 2, NDW * NWAVES>(a, reinterpret_cast<unsigned char*>(fast_lds) + wv * BL::BYTES, bseg, b & 7, gi);
+      return;
+    }
+    const int sid = blockIdx.x - a.bord * a.nbseg;
     const int per_seg = a.strips * a.npairs;
-    segi = blockIdx.x / per_seg;
-    const int b = blockIdx.x - segi * per_seg;
+    segi = sid / per_seg;
+    const int b = sid - segi * per_seg;
     const int full = (a.npairs / 8) * 8 * bpp;          // ids covered by complete groups of 8 pairs
     int p, inner;
     if (b < full) {
@@ -642,13 +620,23 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
   }
 }
 
+#if defined(SBM_DEV_PROF) && !SBM_FAST_PINGPONG
+// profiling builds: read and clear the border row-loop cycle counters (tools/exp/r04_bwprof.py)
+extern "C" int sbm_dev_bw_prof(unsigned long long* out8) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bw_prof), sizeof(z)) != hipSuccess) return -2;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bw_prof), z, sizeof(z)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 #if !SBM_FAST_PINGPONG
 hipError_t launch_sad_fast_pp(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
-                              int* xa, int* xb, hipStream_t s);
+                              int* xa, int* xb, bool border, hipStream_t s);
 
 // Device check behind the in-place accumulate: v_mqsad_pk_u16_u8 with vdst == src2 against the compiler's
 // non-aliased form, pseudo-random operands, single instructions and dependent chains (tools/ubench/mqsad_alias.hip
-// is the long version). One wavefront per SIMD-pair, a few microseconds, once per device and process.
+// is the long version); three short launches, once per device and process.
 __global__ void __launch_bounds__(256) mqsad_inplace_selftest_kernel(unsigned* bad) {
   unsigned long long st = (unsigned long long)(blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 88172645463325252ull;
   auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
@@ -669,33 +657,44 @@ __global__ void __launch_bounds__(256) mqsad_inplace_selftest_kernel(unsigned* b
     for (int q = 0; q < 4; q++) nbad += accA[q] != accR[q];
   }
   if (nbad) atomicAdd(bad, nbad);
+  atomicAdd(bad + 1, 1u);   // "this workgroup's thread ran": a launch that never executed must not read as a pass
 }
 
+// Runs once per device and process (std::call_once: handles may be created from several threads). The check is launched at
+// three occupancies -- 1, 4 and 8 wavefronts per SIMD chip-wide -- and passes only if every thread of every launch reported
+// in and none saw a difference; a failed launch, copy or synchronisation counts as "not ok" (the ping-pong build then runs).
 bool mqsad_inplace_ok(hipStream_t s) {
-  static int state[64];   // per device: 0 unknown, 1 ok, 2 not ok
+  static std::once_flag once[64];
+  static bool ok[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (state[dev] == 0) {
-    static const int env = [] { const char* e = getenv("SBM_FAST_INPLACE"); return e ? atoi(e) : 1; }();
+  std::call_once(once[dev], [&] {
+    ok[dev] = false;
+    if (env_switch("SBM_FAST_INPLACE", 1) == 0) return;
     unsigned* d = nullptr;
-    unsigned h = 1;
-    if (env && hipMalloc(&d, 4) == hipSuccess) {
-      if (hipMemsetAsync(d, 0, 4, s) == hipSuccess) {
-        hipLaunchKernelGGL(mqsad_inplace_selftest_kernel, dim3(64), dim3(256), 0, s, d);
-        if (hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) h = 1;
+    if (hipMalloc(&d, 8) != hipSuccess) return;
+    bool pass = true;
+    const unsigned grids[3] = {256u, 1024u, 2048u};   // x 256 threads = 4 wavefronts per workgroup
+    for (int k = 0; k < 3 && pass; k++) {
+      unsigned h[2] = {1u, 0u};
+      pass = hipMemsetAsync(d, 0, 8, s) == hipSuccess;
+      if (pass) {
+        hipLaunchKernelGGL(mqsad_inplace_selftest_kernel, dim3(grids[k]), dim3(256), 0, s, d);
+        pass = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+               hipStreamSynchronize(s) == hipSuccess && h[0] == 0u && h[1] == grids[k] * 256u;
       }
-      hipFree(d);
     }
-    state[dev] = (env && h == 0) ? 1 : 2;
-  }
-  return state[dev] == 1;
+    (void)hipFree(d);
+    ok[dev] = pass;
+  });
+  return ok[dev];
 }
 
 // Pre-scaled planes for the tagged winner search: (value << sh) + 1 must fit a byte and (maxS << sh) + tag a packed half;
 // the uniqueness envelope is the one of sad_fast_supported() on the scaled sums. SBM_FAST_PFSHIFT=0 turns it off, =1 limits
 // it to one tag bit.
 int sad_fast_pfshift(const Geom& g) {
-  static const int env = [] { const char* e = getenv("SBM_FAST_PFSHIFT"); return e ? atoi(e) : 2; }();
+  static const int env = env_switch("SBM_FAST_PFSHIFT", 2);
   if (env <= 0 || !sad_fast_supported(g)) return 0;
   const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
   // the kernels hold one tagged variant each: two tag bits (4 v + 1) for windows up to 15, one (2 v + 1) above
@@ -716,6 +715,7 @@ bool sad_fast_supported(const Geom& g) {
   if (maxs > 65534) return false;
   if (2 * (maxs * g.uniq / 100 + 1) >= 65535) return false;
   if (g.row0 < g.w2 || g.row1 > g.H - g.w2 || g.row1 <= g.row0) return false;
+  if ((long)g.plane * 4 >= (1L << 31)) return false;   // a border wavefront reaches up to 4 pairs through 32-bit offsets
   const int xhi = std::min(g.W - g.lofs - 1, g.W - g.rofs - g.nd);  // last unclamped window column
   if (xhi - g.w2 + 1 <= g.w2) return false;
   return true;
@@ -723,11 +723,39 @@ bool sad_fast_supported(const Geom& g) {
 #endif  // !SBM_FAST_PINGPONG
 
 template <int NDW, int NWAVES, int NTERM, int PW>
-static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
+static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   constexpr bool DUAL = PW == 3;
   constexpr int WSLOT1 = FastLds<NDW, NTERM, PW, 1>::WSLOT, WSLOT3 = FastLds<NDW, NTERM, PW, DUAL ? 3 : 1>::WSLOT;
   constexpr int WSLOTM = WSLOT1 > WSLOT3 ? WSLOT1 : WSLOT3;
-  const size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  a.bord = a.bgx = 0;
+  a.bpstride = 8;
+  if (border) {
+    // border wavefronts per segment: 2 sides x ceil(n / (8 JW)) pair groups for each of the 8 XCD residues, NWAVES per workgroup
+    using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
+    a.bgx = 2 * ((a.npairs + 8 * BL::JW - 1) / (8 * BL::JW));
+    a.bord = 8 * ((a.bgx + NWAVES - 1) / NWAVES);
+    if ((long)(BL::JW - 1) * 8 * a.plane + a.plane >= (1L << 31)) a.bpstride = 1;   // (JW - 1) * plane < 2^31: sad_fast_supported()
+    lds = std::max(lds, (size_t)NWAVES * BL::BYTES);
+    // A border wavefront is a serial chain of rows (~2 us + 0.25 us per output column and row, a quarter of that for each of
+    // its w-1 priming rows -- measured alone on the chip, tools/exp/r04_bwprof.py); it must end well inside the launch, so the
+    // border jobs get their own, finer row segments: a chain of about a quarter of the launch's expected duration.
+    const int rows = a.row1 - a.row0, wsz = PW * NTERM;
+    const double t_kernel_us = (double)a.npairs * a.W * rows * a.nd / 3.6e12 * 1e6;
+    const double t_row_us = 2.0 + 0.25 * (wsz / 2);
+    int bseg = (int)(0.25 * t_kernel_us / t_row_us - 0.25 * (wsz - 1));
+    bseg = SBM_TUNE("SBM_DEV_BSEG", bseg);
+    bseg = std::max(4, std::min(bseg, rows));
+    a.nbseg = (rows + bseg - 1) / bseg;
+    a.bseg = (rows + a.nbseg - 1) / a.nbseg;
+    a.nbseg = (rows + a.bseg - 1) / a.bseg;
+  } else {
+    a.bseg = a.row1 - a.row0;
+    a.nbseg = 0;
+  }
+  dim3 grid((unsigned)(a.bord * a.nbseg + a.strips * a.npairs * a.nseg));
+  // development builds: time the border wavefronts alone (results are wrong by construction)
+  if (SBM_TUNE("SBM_DEV_BORDER_ONLY", 0)) grid.x = (unsigned)(a.bord * a.nbseg);
   snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
            NDW, NWAVES, NTERM, PW, a.nd == NDW * NWAVES ? "true" : "false", DUAL ? "true" : "false", a.pfshift);
   if (a.nd == NDW * NWAVES)
@@ -742,30 +770,30 @@ static hipError_t launch_t(const FastArgs& a, dim3 grid, hipStream_t s) {
 // in-place accumulate), two cooperate up to nd 256.  mode 0 (SBM_FAST_MODE=0, and the ping-pong build): 64 disparities
 // per wavefront, nd/64 cooperating wavefronts -- the round-1/2 layout, kept for A/B measurements and as the fallback.
 template <int NTERM, int PW>
-static hipError_t launch_nd(const FastArgs& a, dim3 grid, int mode, bool split, hipStream_t s) {
-  if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, grid, s);
-  if (a.nd == 48) return launch_t<32, 2, NTERM, PW>(a, grid, s);   // the masked single-wavefront variant needs 174 VGPRs
+static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split, hipStream_t s) {
+  if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, border, s);
+  if (a.nd == 48) return launch_t<32, 2, NTERM, PW>(a, border, s);   // the masked single-wavefront variant needs 174 VGPRs
   // one-pair calls: too few workgroups to fill the chip, so split the disparities over two wavefronts (half the serial work
   // per row; SBM_FAST_SPLIT=0 disables)
-  if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW>(a, grid, s);
-  if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, grid, s);
+  if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW>(a, border, s);
+  if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, border, s);
   // (two cooperating 128-disparity wavefronts at nd 256 -- SBM_FAST_MODE=2 -- run the interior kernel 7 % faster but starve
   // the border kernel until it has drained: 1080p step 3.13 -> 3.26 ms, profiles/r03_sad_isa_budget.md)
-  if (mode >= 1 && !split && a.nd <= 128) return launch_t<128, 1, NTERM, PW>(a, grid, s);
-  if (mode == 2 && !split && a.nd > 192) return launch_t<128, 2, NTERM, PW>(a, grid, s);
-  if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, grid, s);
-  if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, grid, s);
-  return launch_t<64, 4, NTERM, PW>(a, grid, s);
+  if (mode >= 1 && !split && a.nd <= 128) return launch_t<128, 1, NTERM, PW>(a, border, s);
+  if (mode == 2 && !split && a.nd > 192) return launch_t<128, 2, NTERM, PW>(a, border, s);
+  if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, border, s);
+  if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, border, s);
+  return launch_t<64, 4, NTERM, PW>(a, border, s);
 }
 
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
-                           int* xa, int* xb, hipStream_t s) {
+                           int* xa, int* xb, bool border, hipStream_t s) {
   *xa = *xb = 0;
   if (!sad_fast_supported(g)) return hipSuccess;
 #if !SBM_FAST_PINGPONG
-  if (!mqsad_inplace_ok(s)) return launch_sad_fast_pp(pf_l, pf_r, disp, cost, g, xa, xb, s);
+  if (!mqsad_inplace_ok(s)) return launch_sad_fast_pp(pf_l, pf_r, disp, cost, g, xa, xb, border, s);
 #endif
-  static const int mode = [] { const char* e = getenv("SBM_FAST_MODE"); return e ? atoi(e) : (SBM_FAST_PINGPONG ? 0 : 1); }();
+  static const int mode = env_switch("SBM_FAST_MODE", SBM_FAST_PINGPONG ? 0 : 1);
   FastArgs a;
   a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? reinterpret_cast<uint16_t*>(cost) : nullptr;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
@@ -778,7 +806,7 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   const int nv = 64 - (g.wsz - pw);
   // windows that are multiples of 3: triples of column-stride-3 strips (3 * nv3 columns each) as far as they pay, plain
   // strips for the rest (SBM_FAST_CS3=0: plain strips only)
-  static const int cs3_env = [] { const char* e = getenv("SBM_FAST_CS3"); return e ? atoi(e) : 1; }();
+  const int cs3_env = env_switch("SBM_FAST_CS3", 1);   // read per call (the GPU tests flip it)
   const int ncols = a.xc1 - a.xc0;
   const int nv3 = 64 - (g.wsz / 3 - 1);
   int triples = 0;
@@ -796,15 +824,19 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   // but let the border kernel finish earlier (KITTI x64, 4 instead of 6 segments: 1.100 + 0.053 -> 1.115 + 0.028 ms;
   // tools/exp/r02_target.sh: 5600 is never worse than 9000 or 4500 on any of the bench workloads)
   int nseg = 1;
-  static const long target = [] { const char* e = getenv("SBM_FAST_TARGET"); return e ? atol(e) : 5600L; }();
+  // Round 4: with the border columns inside this launch (no second kernel whose tail grows with the segment count) finer
+  // segments pay where one wavefront is a workgroup: KITTI x64 1.099 -> 1.081 ms per step at 11 000 - 32 000 (flat), 640x480
+  // flat, the cooperating-wavefront kernels (nd > 128) best at 4 000 - 5 600 (profiles/r04_border_fused_sweep*.txt)
+  static const long target_env = SBM_TUNE("SBM_FAST_TARGET", 0);
+  const long target = target_env > 0 ? target_env : (g.nd > 128 ? 5600L : 24000L);
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 3 * g.wsz) nseg++;
   // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
   // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
   while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= g.wsz && nseg < 32) nseg++;
-  static const int nseg_env = [] { const char* e = getenv("SBM_FAST_NSEG"); return e ? atoi(e) : 0; }();
+  static const int nseg_env = SBM_TUNE("SBM_FAST_NSEG", 0);
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
   // taper: the last third of the rows is cut into segments of 2/3, 1/2, 1/3 ... of the regular length
-  static const int taper = [] { const char* e = getenv("SBM_FAST_TAPER"); return e ? atoi(e) : 1; }();
+  static const int taper = SBM_TUNE("SBM_FAST_TAPER", 1);
   nseg = std::min(nseg, 32);
   int ns = 0;
   a.segrow[0] = g.row0;
@@ -826,26 +858,31 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   a.strips = strips; a.nseg = nseg; a.npairs = g.n;
   {
     const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
-    static const int plain_env = [] { const char* e = getenv("SBM_FAST_UNIQ_PLAIN"); return e ? atoi(e) : 1; }();
+    static const int plain_env = SBM_TUNE("SBM_FAST_UNIQ_PLAIN", 1);
     a.uniq_plain = plain_env && 8 * ((maxs * g.uniq / 100 + 1) << g.pfshift) <= 65535;   // (8 registers per accumulator)
   }
-  dim3 grid((unsigned)strips * nseg * g.n);
-  static const int split_env = [] { const char* e = getenv("SBM_FAST_SPLIT"); return e ? atoi(e) : 1; }();
-  const bool split = grid.x < 1024 && split_env;
+  static const int split_env = SBM_TUNE("SBM_FAST_SPLIT", 1);
+  const bool split = (long)strips * nseg * g.n < 1024 && split_env;
   hipError_t e;
   switch (g.wsz) {
-    case 9: e = launch_nd<3, 3>(a, grid, mode, split, s); break;
-    case 15: e = launch_nd<5, 3>(a, grid, mode, split, s); break;
-    case 21: e = launch_nd<7, 3>(a, grid, mode, split, s); break;
-    case 27: e = launch_nd<9, 3>(a, grid, mode, split, s); break;
-    case 5: e = launch_nd<5, 1>(a, grid, mode, split, s); break;
-    case 7: e = launch_nd<7, 1>(a, grid, mode, split, s); break;
-    case 11: e = launch_nd<11, 1>(a, grid, mode, split, s); break;
-    case 13: e = launch_nd<13, 1>(a, grid, mode, split, s); break;
-    case 17: e = launch_nd<17, 1>(a, grid, mode, split, s); break;
-    case 19: e = launch_nd<19, 1>(a, grid, mode, split, s); break;
-    case 23: e = launch_nd<23, 1>(a, grid, mode, split, s); break;
-    default: e = launch_nd<25, 1>(a, grid, mode, split, s); break;
+#ifdef SBM_DEV_FEW   // development builds (tools/exp): only the bench workloads' windows are instantiated
+    case 15: e = launch_nd<5, 3>(a, border, mode, split, s); break;
+    case 21: e = launch_nd<7, 3>(a, border, mode, split, s); break;
+    default: e = hipErrorInvalidValue; break;
+#else
+    case 9: e = launch_nd<3, 3>(a, border, mode, split, s); break;
+    case 15: e = launch_nd<5, 3>(a, border, mode, split, s); break;
+    case 21: e = launch_nd<7, 3>(a, border, mode, split, s); break;
+    case 27: e = launch_nd<9, 3>(a, border, mode, split, s); break;
+    case 5: e = launch_nd<5, 1>(a, border, mode, split, s); break;
+    case 7: e = launch_nd<7, 1>(a, border, mode, split, s); break;
+    case 11: e = launch_nd<11, 1>(a, border, mode, split, s); break;
+    case 13: e = launch_nd<13, 1>(a, border, mode, split, s); break;
+    case 17: e = launch_nd<17, 1>(a, border, mode, split, s); break;
+    case 19: e = launch_nd<19, 1>(a, border, mode, split, s); break;
+    case 23: e = launch_nd<23, 1>(a, border, mode, split, s); break;
+    default: e = launch_nd<25, 1>(a, border, mode, split, s); break;
+#endif
   }
   *xa = a.xc0; *xb = a.xc1;
   return e;

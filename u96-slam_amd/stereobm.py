@@ -9,6 +9,7 @@ src/slam/src/core/main.cpp:201-215 of the reference:
 (device path, sbm_compute_device; torch is used for device memory only). Parameter errors raise StereoBMError
 with the status code and OpenCV's message, where cv::StereoBM::compute would throw cv::Error.
 """
+import collections
 import ctypes
 import os
 import pathlib
@@ -100,8 +101,17 @@ class StereoBMError(RuntimeError):
 
 
 def library_path():
-    # SBM_LIB_AB=<file name inside lib/>: A/B builds of the same HIP engine for kernel experiments (tools/exp); never a fallback
-    return _HERE / "lib" / os.environ.get("SBM_LIB_AB", "libsbm_hip.so")
+    """lib/libsbm_hip.so, or -- SBM_LIB_AB=<file name> -- another build of the same HIP engine inside lib/ for kernel A/B
+    runs (tools/exp). Only a bare libsbm_hip*.so name is accepted and the file must exist: never a fallback, never a path."""
+    name = os.environ.get("SBM_LIB_AB", "libsbm_hip.so")
+    if name != os.path.basename(name) or not (name.startswith("libsbm_hip") and name.endswith(".so")):
+        raise ImportError(f"SBM_LIB_AB={name!r}: expected the bare name of a libsbm_hip*.so inside {_HERE / 'lib'}")
+    return _HERE / "lib" / name
+
+
+def loaded_library_name():
+    """File name of the engine library this process uses (bench.py prints it)."""
+    return library_path().name
 
 
 def load_library():
@@ -188,7 +198,8 @@ class StereoBM:
         L.sbm_params_default(ctypes.byref(self._p), numDisparities, blockSize)
         self._h = ctypes.c_void_p()
         self._device = device
-        self._inflight = []
+        self._inflight = []                   # buffers of asynchronous compute_device calls, until synchronize()
+        self._host_inflight = collections.deque()   # (left, right, disparity) of submit_host, oldest first
         _check(L.sbm_create(ctypes.byref(self._h), ctypes.byref(self._p), device))
 
     @staticmethod
@@ -296,12 +307,17 @@ class StereoBM:
         if left.shape != right.shape or left.shape != disparity.shape:
             raise StereoBMError(-2, "All the images must have the same size")
         n, h, w = left.shape
+        # the engine drains to at most two outstanding submissions before it queues this one (sbm_submit_dense)
+        while len(self._host_inflight) > 2:
+            self._host_inflight.popleft()
         _check(self._L.sbm_submit_dense(self._h, n, left.ctypes.data, right.ctypes.data, w, h, disparity.ctypes.data), self._h)
-        self._inflight.append((left, right, disparity))
+        self._host_inflight.append((left, right, disparity))
 
     def wait_host(self):
         """sbm_wait_oldest: block until the oldest outstanding submit_host() has delivered its maps."""
         _check(self._L.sbm_wait_oldest(self._h), self._h)
+        if self._host_inflight:
+            self._host_inflight.popleft()     # its arrays are the caller's again
 
     def compute_device(self, left, right, disparity=None, sync=True):
         """Device-resident batch: torch CUDA uint8 tensors (n,H,W) or (H,W), contiguous. Returns a torch int16 tensor."""
@@ -335,7 +351,9 @@ class StereoBM:
             # (a list: back-to-back asynchronous calls each keep their buffers until the next synchronize())
             self._inflight.append((left, right, disparity))
         else:
-            self._inflight.clear()   # a synchronous call drains the engine's stream: earlier asynchronous calls are done too
+            # a synchronous call drains the engine's compute stream: earlier asynchronous DEVICE calls are done too
+            # (host submissions keep their arrays: their maps may still be on the way home on the copy stream)
+            self._inflight.clear()
         return disparity
 
     def _check_device_images(self, *tensors):
@@ -506,6 +524,7 @@ class StereoBM:
     def synchronize(self):
         _check(self._L.sbm_synchronize(self._h), self._h)
         self._inflight.clear()   # buffers of asynchronous compute_device calls may be released now
+        self._host_inflight.clear()
 
     def stream(self):
         return self._L.sbm_stream(self._h)
