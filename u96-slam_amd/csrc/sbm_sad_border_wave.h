@@ -101,8 +101,13 @@ struct BorderLds {
 };
 
 // One border wavefront: side (gi & 1) of the pairs pair0 + k * pstride (k < JW), rows of segment segi.
+// The LDS of the wavefront comes in as three `restrict` areas -- staged rows (+ zero patterns), finishing entries, texture
+// sums: the rows arrive by LDS-direct loads, and the compiler makes every LDS access that MAY alias a pending one wait for
+// it (vmcnt); the scoped no-alias information of the three parameters is what lets the winner search's own LDS traffic run
+// while the next rows are still in flight.
 template <int W2, int NDMAX>
-__device__ __forceinline__ void sad_border_wave(const FastArgs& a, unsigned char* const wl, const int segi, const int x8, const int gi) {
+__device__ __forceinline__ void sad_border_wave_body(const FastArgs& a, unsigned char* __restrict__ const wl, uint4* __restrict__ const Ep,
+                                                     int* __restrict__ const Tc, const int segi, const int x8, const int gi) {
   using BL = BorderLds<W2, NDMAX>;
   constexpr int NVC = 3 * W2, WSZ = 2 * W2 + 1;
   constexpr int JW = BL::JW, GL = 64 / JW;
@@ -142,8 +147,6 @@ __device__ __forceinline__ void sad_border_wave(const FastArgs& a, unsigned char
   // LDS carve-up: staged row `which` = right entries [job][p & 3][p >> 2] (8 B each), then left dwords [job][v]
   constexpr int ROWB = BL::RB + BL::LB;
   unsigned char* const Zb = wl + 2 * ROWB;                        // NVC zero dwords
-  uint4* const Ep = reinterpret_cast<uint4*>(Zb + BL::ZB);
-  int* const Tc = reinterpret_cast<int*>(Zb + BL::ZB + BL::EP);
   if (lane < NVC) reinterpret_cast<u32*>(Zb)[lane] = 0u;
 
   const size_t jobstride = (size_t)pstride * a.plane;             // bytes between the planes of two jobs (< 2^31 / 4: host-checked)
@@ -406,4 +409,11 @@ __device__ __forceinline__ void sad_border_wave(const FastArgs& a, unsigned char
 #endif
   }
   flush();        // the segment's last row
+}
+
+template <int W2, int NDMAX>
+__device__ __forceinline__ void sad_border_wave(const FastArgs& a, unsigned char* const wl, const int segi, const int x8, const int gi) {
+  using BL = BorderLds<W2, NDMAX>;
+  unsigned char* const rest = wl + 2 * (BL::RB + BL::LB) + BL::ZB;
+  sad_border_wave_body<W2, NDMAX>(a, wl, reinterpret_cast<uint4*>(rest), reinterpret_cast<int*>(rest + BL::EP), segi, x8, gi);
 }
