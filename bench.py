@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (0 = workload default)")
     ap.add_argument("--block", type=int, default=0, help="override the SAD window")
+    ap.add_argument("--ndisp", type=int, default=0, help="override the number of disparities (experiments)")
     ap.add_argument("--no-postfilter", action="store_true", help="SAD/WTA/texture/uniqueness only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
@@ -211,6 +212,8 @@ def main():
     W, H, nd, wsz, pairs_default = WORKLOADS[args.workload]
     if args.block:
         wsz = args.block
+    if args.ndisp:
+        nd = args.ndisp
     B = args.pairs or pairs_default
     post = not args.no_postfilter
 
@@ -513,7 +516,15 @@ def main():
             try:
                 tj = json.loads(tfile.read_text())
                 key = f"{args.workload}_w{wsz}_b{B}"
-                if key in tj and tj[key].get("kernel") and tj[key]["kernel"] != kernel_name:
+                sys.path.insert(0, str(ROOT / "tools"))
+                import publish_profiles
+
+                here = publish_profiles.source_hash(ROOT)
+                if key in tj and tj[key].get("source_hash") and tj[key]["source_hash"] != here:
+                    # same kernel name, other sources: counters of another build are never attached to this one
+                    pmc_extra = {"traffic_reason": f"profiles/hbm_traffic.json[{key}] was measured on engine sources {tj[key]['source_hash']}, this tree "
+                                                   f"is {here}: re-run tools/profile_round.sh"}
+                elif key in tj and tj[key].get("kernel") and tj[key]["kernel"] != kernel_name:
                     # the committed counters were taken on another kernel instantiation: never attach them to this one
                     pmc_extra = {"traffic_reason": f"profiles/hbm_traffic.json[{key}] was measured on '{tj[key]['kernel']}', this run launched "
                                                    f"'{kernel_name}': re-run tools/profile_round.sh"}

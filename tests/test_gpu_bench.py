@@ -157,6 +157,15 @@ def test_engine_variants_are_bit_exact(env, kernel):
     assert j["cpu_baseline"]["bit_exact_vs_gpu"] is True
 
 
+@pytest.mark.parametrize("env,kernel", [
+    ({}, "sad_fast_kernel<128,2,7,3,true,true> pfshift=1"),                      # two 128-disparity wavefronts, LDS-direct staging
+    ({"SBM_FAST_MODE": "1"}, "sad_fast_kernel<64,4,7,3,true,true> pfshift=1"),    # four 64-disparity wavefronts, register-staged
+])
+def test_256_disparities_both_layouts_are_bit_exact(env, kernel):
+    j = _run(["--steps", "2", "--warmup", "1", "--pairs", "4", "--cpu-sample", "2", "--check", "--workload", "fhd", "--prewarm-s", "0"], env=env)
+    assert j["roofline"]["kernel"] == kernel and j["cpu_baseline"]["bit_exact_vs_gpu"] is True
+
+
 def test_reference_window_uses_one_tag_bit():
     j = _run(["--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "8", "--check", "--workload", "ref640"])
     assert j["roofline"]["kernel"] == "sad_fast_kernel<64,1,7,3,true,true> pfshift=1" and j["cpu_baseline"]["bit_exact_vs_gpu"] is True

@@ -152,6 +152,12 @@ struct FastLds {
   static constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
   static_assert(CS == 1 || (CS == 3 && PW == 3), "column stride 3 goes with 3-column sums");
 };
+// Single-wavefront workgroups stage their rows with LDS-direct loads (see sad_fast_strip): two staged rows per wavefront
+// (entering / leaving), the first one doubling as the exchange area.
+// ... and so do two cooperating 128-disparity wavefronts (129..256 disparities): 2 x 2 areas + the merge area still leave six
+// workgroups per CU. The 64-disparity cooperating wavefronts (5 per SIMD) keep the register-staged strip: two staged rows per
+// wavefront would cost them a workgroup per CU.
+constexpr bool fast_dma(int ndw, int nwaves) { return !SBM_FAST_PINGPONG && (nwaves == 1 || (ndw == 128 && nwaves == 2)); }
 
 // One strip of one row segment of one pair: lane i works on column cbase + CS * i (relative to lofs).
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
@@ -565,6 +571,382 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
   }
 }
 
+// The same strip for single-wavefront workgroups, with LDS-DIRECT STAGING (round 4): the right row pieces go from HBM / L2
+// straight into the 16x-expanded LDS layout (buffer_load_dwordx4 ... lds: lane i's 16 source bytes land in slot i), so a row in
+// flight costs no registers (21 VGPRs per row before, two rows in flight at the kernel's pressure peak) and no ds_write_b128
+// (10 per wavefront-row at KITTI size, 16 % of the kernel's LDS-pipe cycles). Two staged-row areas per wavefront: b0 takes the
+// entering row and, once that is consumed, serves as the exchange area; b1 takes the leaving row. Both rows are consumed at
+// the TOP of an output row (leave, then enter), so both areas are free for the rest of the row and the next rows' loads have
+// a whole row to arrive; one s_waitcnt vmcnt(0) per row. A row's results are stored one iteration late, behind that wait.
+// KITTI x64 (same box, alternating, bit-exact): SAD stage 0.910 -> 0.801 ms, step 1.083 -> 0.976 ms; 168 -> 165 VGPRs, 12 -> 0
+// bytes of scratch. The cooperating-wavefront kernels (nd > 128) keep the register-staged strip above: two staged rows per
+// wavefront would cost them a workgroup per CU (LDS).
+// b0 / b1: the wavefront's LDS areas, `restrict` so that the scoped no-alias information lets LDS traffic of one area run
+// while LDS-direct loads into the other are in flight (the compiler makes every LDS access that MAY alias a pending
+// LDS-direct load wait for it).
+template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
+__device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __restrict__ const b0, uint4* __restrict__ const b1, u32* __restrict__ const xkey,
+                                                   const int cbase, const int segi, const int pair) {
+  using L = FastLds<NDW, NTERM, PW, CS>;
+  typedef __attribute__((address_space(3))) void* lds_vptr;
+  constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
+  constexpr int NR = NDW / 2;           // packed pair registers
+  constexpr int NSLOT = L::NSLOT;
+  constexpr int NIT = NSLOT / 64;
+  constexpr int WSZ = PW * NTERM, W2 = WSZ / 2;
+  constexpr int KS = L::KS;
+  constexpr int NV = 64 - KS * (NTERM - 1);   // lanes that produce an output
+  constexpr int XCH = L::XCH, XS = L::XS;
+  constexpr int WSLOT = L::WSLOT;
+
+  const int lane = threadIdx.x & 63;
+  const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const int d0 = wv * NDW;                              // first buffer index of this wavefront
+  const int c = cbase + CS * lane;                      // this lane's column (relative to lofs): V covers c..c+2
+  const int xc = c + W2;                                // centre column this lane produces
+  const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
+  const int ys = a.segrow[segi];
+  const int ye = a.segrow[segi + 1];
+  // wavefront-uniform bases (scalar registers; the per-row step is scalar arithmetic) + this lane's 32-bit offset
+  const uint8_t* pl = a.pf_l + (size_t)pair * a.plane + a.padl + a.lofs + cbase;  // left bytes: + CS * lane
+  const uint8_t* pr = a.pf_r + (size_t)pair * a.plane + a.padl + a.rofs + cbase + d0;  // right piece: window of buffer index d starts at c + d
+  uint2* const xacc = reinterpret_cast<uint2*>(xkey + 2 * NWAVES * 64);   // merge area [2][NWAVES][64] keys, then [2][NWAVES][64] (deficits, neighbours)
+  const unsigned lane_u = (unsigned)lane;
+  // raw buffer descriptors over the rest of this pair's planes (rows of one pair are < 2^31 bytes apart)
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pl), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pr), 0, 0x7fffffff, 0x00020000);
+  // b0 after its staged row has been consumed: the exchange area of the horizontal window
+  uint4* const xq = b0;                                                 // [XCH/2 quad pairs][XS lanes], 8 x u16 each
+  u32* const xt = reinterpret_cast<u32*>(xq + (XCH / 2) * XS);          // [XS] texture column sums
+  const u32 capw = (u32)a.capb * 0x01010101u;
+
+  // vertical sums, packed 4 x u16 per quad (low dword = indices 4q, 4q+1, high dword = 4q+2, 4q+3), accumulated in place
+  // (v_mqsad_pk_u16_u8 with vdst == src2, see sad_fast_strip)
+  u64 VB[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) VB[q] = 0ull;
+  u32 Vt = 0;  // texture: window-row sum of the 3-column |L - cap|
+
+  // buffer_load_dwordx4 ... lds: lane i of load `it` writes its 16 source bytes (row piece bytes 64 it + i .. + 15: a byte-
+  // granular source address is fine, tools/ubench/lds_dma.hip) to LDS slot 64 it + i -- the 16x-expanded layout without a
+  // staging register or a ds_write. The lanes' left patterns follow as 64 dwords behind the area's WSLOT slots (pat_of()).
+  auto pat_of = [](uint4* const buf) { return reinterpret_cast<u32*>(buf + WSLOT); };
+  auto stage = [&](const int y, uint4* const buf) {
+    const int rowoff = __builtin_amdgcn_readfirstlane(y * a.pitch);
+#pragma unroll
+    for (int it = 0; it < NIT; it++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(buf + 64 * it), 16, (int)lane_u, rowoff + 64 * it, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lds_vptr)pat_of(buf), 4, (int)(CS * lane_u), rowoff, 0, 0);
+  };
+  auto landed = [] {        // everything this wavefront has in flight has landed (LDS-direct loads count in vmcnt)
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto reads_done = [] {    // every LDS read of this wavefront has returned (lgkmcnt = 0): an area may be overwritten
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // the staged row in `buf` enters (leave == false) or leaves the vertical sums
+  auto apply = [&](uint4* const buf, const bool leave) {
+    constexpr u32 PMASK = PW == 3 ? 0x00ffffffu : 0x000000ffu;
+    const u32 pat = pat_of(buf)[lane] & PMASK;  // remaining bytes = 0 -> masked by mqsad
+    const u32 tv = __builtin_amdgcn_sad_u8(pat | (capw & ~PMASK), capw, 0u);
+    // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments
+    // (lane stride CS * 16 bytes: 16 consecutive lanes hit 64 distinct banks for CS = 1 and for CS = 3).
+    const uint4* const win_lds = buf + CS * lane;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += 16) {
+      constexpr int NM = 4;
+      uint4 ra[NM], rb[NM];
+#pragma unroll
+      for (int m = 0; m < NM; m++) {
+        ra[m] = win_lds[16 * (q0 / 4 + m)];
+        rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
+      }
+#pragma unroll
+      for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
+        const int q = q0 + qq;
+        // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
+        u32 lo, hi;
+        if ((qq & 1) == 0) {
+          const uint4 v = ra[qq >> 2];
+          lo = (qq & 2) ? v.z : v.x;
+          hi = (qq & 2) ? v.w : v.y;
+        } else {
+          const uint4 v = rb[(qq - 1) >> 2];
+          lo = ((qq - 1) & 2) ? v.z : v.x;
+          hi = ((qq - 1) & 2) ? v.w : v.y;
+        }
+        const u64 win = ((u64)hi << 32) | lo;
+        if (!leave) {
+          asm("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(VB[q]) : "v"(win), "v"(pat));
+        } else {
+          const uint2 tt = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull));
+          uint2 vb = __builtin_bit_cast(uint2, VB[q]);
+          vb.x -= tt.x;                                         // no u16 lane borrows: every partial sum is exact
+          vb.y -= tt.y;
+          // (opaque: with the entering row's in-place accumulate right behind it the compiler otherwise turns the two
+          // subtractions into a 64-bit subtract with a carry chain -- three slow instructions instead of two fast ones)
+          asm("" : "+v"(vb.x), "+v"(vb.y));
+          VB[q] = __builtin_bit_cast(u64, vb);
+        }
+      }
+    }
+    Vt = leave ? Vt - tv : Vt + tv;
+  };
+
+  // prime: rows ys-W2 .. ys+W2-1 alternate between the two areas, the next one arriving while one is consumed; the last one
+  // staged (into b0) is row ys+W2, the first output row's entering row
+  stage(ys - W2, b0);
+  for (int i = 0; i < 2 * W2; i += 2) {
+    landed();
+    stage(ys - W2 + i + 1, b1);
+    apply(b0, false);
+    landed();
+    stage(ys - W2 + i + 2, b0);
+    apply(b1, false);
+  }
+  // outputs through buffer stores: per-pair descriptors, this lane's byte offset, the row in a scalar register. A row's
+  // results leave one iteration late, behind the wait at the top of the next row -- that wait covers everything this wavefront
+  // has in flight, and stores issued at the end of a row would put their whole latency there.
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.disp + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a.cost + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
+  const int ocol = 2 * (a.lofs + xc);
+  int out_prev = 0, cost_prev = -1;
+  auto flush = [&](const int yrow) {
+    if (produces && (NWAVES == 1 || (yrow % NWAVES) == wv)) {   // (this wavefront finished that row)
+      const int orow_prev = __builtin_amdgcn_readfirstlane(2 * yrow * a.W);
+      if (cost_prev >= 0) __builtin_amdgcn_raw_buffer_store_b16((short)cost_prev, rs_c, ocol, orow_prev, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)out_prev, rs_d, ocol, orow_prev, 0);
+    }
+  };
+  for (int y = ys; y < ye; y++) {
+    // b0: entering row y+W2; b1 (y > ys): leaving row y-W2-1. Both are consumed here, so both areas are free for the rest of
+    // the row and the next rows' loads have a whole row to arrive.
+    landed();
+    if (y > ys) {
+      flush(y - 1);
+      apply(b1, true);
+    }
+    // (unconditional, like the entering row below: a branch here would let the compiler sink the exchange's 4 NR adds
+    // below it -- and spill the 4 NR registers they read; the last iteration stages rows nobody consumes)
+    reads_done();
+    stage(y - W2, b1);
+    apply(b0, false);
+
+    // issue priority while this wavefront is in its exchange (a chain of LDS round trips with a few adds behind each): see
+    // sad_fast_strip
+    __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
+    // ---- horizontal window across lanes: S(c + w/2) = sum_k V(c + PW k) through LDS ------------------------------------
+    u32 S[NR];
+    xt[lane] = Vt;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += XCH) {
+      // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
+#pragma unroll
+      for (int qq = 0; qq < XCH; qq += 2) {
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
+        xq[(qq / 2) * XS + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int qq = 0; qq < XCH; qq += 2) {
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
+        u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
+#pragma unroll
+        for (int k = 1; k < NTERM; k++) {
+          const uint4 r = xq[(qq / 2) * XS + lane + KS * k];
+          s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
+          s1 += r.y;
+          s2 += r.z;
+          s3 += r.w;
+        }
+        S[2 * (q0 + qq)] = s0;
+        S[2 * (q0 + qq) + 1] = s1;
+        S[2 * (q0 + qq) + 2] = s2;
+        S[2 * (q0 + qq) + 3] = s3;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (!EXACT_ND) {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        if (d0 + 2 * j >= a.nd) S[j] = 0xffffffffu;
+    }
+    // the texture partners are read now (the exchange area is about to receive the next entering row); the verdict crosses
+    // the winner search as a wavefront-uniform mask, not in a vector register
+    unsigned long long tex_ok;
+    {
+      int tsum = (int)Vt;
+#pragma unroll
+      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + KS * k];
+      tex_ok = __ballot(tsum >= a.tex);
+    }
+    reads_done();
+    stage(min(y + 1 + W2, a.H - 1), b0);
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- WTA: first index attaining the minimum (see sad_fast_strip for the three variants) --------------------------------
+    u32 best = 0xffffffffu;
+    constexpr int TSMAX = WSZ <= 15 ? 2 : 1;
+    if (NR >= 16 && TSMAX == 2 && a.pfshift == 2) {
+      constexpr int NG = NR / 4;
+      u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+      for (int j = 0; j < NG; j++) {
+        const u32 g01 = pk_min(S[j], S[j + NG] | 0x00010001u);
+        const u32 g23 = pk_min(S[j + 2 * NG] | 0x00020002u, S[j + 3 * NG] | 0x00030003u);
+        const u32 gm = pk_min(g01, g23);
+        const u32 klo = (gm << 16) | (u32)(2 * j);
+        const u32 khi = (gm & 0xffff0000u) | (u32)(2 * j + 1);
+        b[j & 3] = umin3(b[j & 3], klo, khi);
+      }
+      const u32 bt = min(min(b[0], b[1]), min(b[2], b[3]));       // (4 S + tag) << 16 | low index bits
+      best = (bt & 0xfffc0000u) | (((bt >> 16) & 3u) * (u32)(2 * NG) + (bt & 0xffffu));
+    } else if (NR >= 16 && TSMAX == 1 && a.pfshift == 1) {
+      constexpr int NG = NR / 2;
+      u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      const u32 tag1 = 0x00010001u;
+#pragma unroll
+      for (int j = 0; j < NG; j++) {
+        const u32 gm = pk_min(S[j], S[j + NG] | tag1);
+        const u32 klo = (gm << 16) | (u32)(2 * j);
+        const u32 khi = (gm & 0xffff0000u) | (u32)(2 * j + 1);
+        b[j & 3] = umin3(b[j & 3], klo, khi);
+      }
+      const u32 bt = min(min(b[0], b[1]), min(b[2], b[3]));       // (2 S + tag) << 16 | low index bits
+      best = (bt & 0xfffe0000u) | (((bt >> 16) & 1u) * (u32)(2 * NG) + (bt & 0xffffu));
+    } else {
+#pragma unroll
+      for (int g0 = 0; g0 < NR; g0 += 32) {
+        u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int j = g0; j < g0 + 32 && j < NR; j++) {
+          const u32 klo = (S[j] << 16) | (u32)(2 * (j - g0));
+          const u32 khi = (S[j] & 0xffff0000u) | (u32)(2 * (j - g0) + 1);
+          b[j & 3] = umin3(b[j & 3], klo, khi);
+        }
+        const u32 bg = min(min(b[0], b[1]), min(b[2], b[3])) + (u32)(2 * g0);
+        best = min(best, bg);
+      }
+    }
+    best += (u32)d0;
+    const int par = y & 1, mpar = par * NWAVES * 64;   // the merge arrays alternate by row parity
+    if constexpr (NWAVES > 1) {
+      xkey[mpar + wv * 64 + lane] = best;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < NWAVES; w++) best = min(best, xkey[mpar + w * 64 + lane]);
+    }
+    const int minsad = (int)(best >> 16), mind = (int)(best & 0xffffu);
+
+    // ---- uniqueness (part 1): saturating sum of the deficits max(T - S[d], 0), per 16-bit half --------------
+    u32 acc = 0, T = 0;
+    if (a.uniq > 0) {
+      const int ms = minsad >> a.pfshift;                     // the threshold is defined on the unscaled sum
+      const int thresh = ms + (ms * a.uniq / 100);
+      T = (u32)min((thresh + 1) << a.pfshift, 65535);
+      const u32 T2 = T | (T << 16);
+      constexpr int NACC = NR >= 32 ? NR / 8 : 4;
+      u32 ac[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; k++) ac[k] = 0u;
+      if (a.uniq_plain) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) ac[j % NACC] += pk_sub_sat(T2, S[j]);
+      } else {
+        // (an opaque copy of the threshold: otherwise the compiler hoists the NR subtractions both paths share above
+        // the branch and keeps all of them live at once)
+        u32 T2s = T2;
+        asm("" : "+v"(T2s));
+#pragma unroll
+        for (int j = 0; j < NR; j++) ac[j % NACC] = pk_add_sat(ac[j % NACC], pk_sub_sat(T2s, S[j]));
+      }
+#pragma unroll
+      for (int n = NACC; n > 1; n >>= 1)
+#pragma unroll
+        for (int k = 0; k < n / 2; k++) ac[k] = pk_add_sat(ac[k], ac[k + n / 2]);
+      acc = ac[0];
+    }
+
+    // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
+    const int in_ = mind > 0 ? mind - 1 : 1;
+    const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
+    const int ln = min(max(in_ - d0, 0), NDW - 1), lp = min(max(ip_ - d0, 0), NDW - 1);  // local (clamped) indices
+    u32 X[NQ];
+    const u32 lnp = (u32)ln | ((u32)lp << 16);
+    {
+      // bytes (2a, 2a+1) with a = index & 3:  0x0100 + a * 0x0202 per half
+      const u32 sel = __umul24(lnp & 0x00030003u, 0x0202u) + 0x01000100u;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
+    }
+    {
+      int lvl = 2;
+#pragma unroll
+      for (int n = NQ; n > 1; n >>= 1) {
+        const u32 sel = __umul24((lnp >> lvl) & 0x00010001u, 0x0404u) + 0x03020100u;
+#pragma unroll
+        for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
+        lvl++;
+      }
+    }
+    int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
+    u32 acc_lo = acc & 0xffffu, acc_hi = acc >> 16;
+    bool mine = true;  // does this wavefront finalise this row?
+    if constexpr (NWAVES > 1) {
+      xacc[mpar + wv * 64 + lane] = make_uint2(acc, X[0]);
+      __syncthreads();
+      mine = (y % NWAVES) == wv;
+      if (mine) {
+        acc_lo = acc_hi = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) {
+          const u32 aw = xacc[mpar + w * 64 + lane].x;
+          acc_lo += aw & 0xffffu;
+          acc_hi += aw >> 16;
+        }
+        nn = (int)(xacc[mpar + (in_ / NDW) * 64 + lane].y & 0xffffu);   // owner wavefront of index in_
+        pp = (int)(xacc[mpar + (ip_ / NDW) * 64 + lane].y >> 16);       // owner wavefront of index ip_
+      }
+    }
+
+    bool ok = __builtin_amdgcn_inverse_ballot_w64(tex_ok);
+    // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
+    if (a.uniq > 0) {
+      const u32 dm = T - (u32)minsad;                                     // >= 1
+      const u32 dn = (mind > 0 && (u32)nn < T) ? T - (u32)nn : 0u;         // S[mind-1] exists
+      const u32 dp = (mind < a.nd - 1 && (u32)pp < T) ? T - (u32)pp : 0u;  // S[mind+1] exists
+      const u32 e_same = dm, e_other = dn + dp;                            // mind's parity half / the other half
+      const u32 exp_lo = (mind & 1) ? e_other : e_same, exp_hi = (mind & 1) ? e_same : e_other;
+      ok = ok && acc_lo == exp_lo && acc_hi == exp_hi;
+    }
+    if (mine && produces) {
+      int out = a.filtered, cst = -1;
+      if (ok) {
+        const int ad = pp > nn ? pp - nn : nn - pp;
+        const int den = pp + nn - 2 * minsad + ad;
+        int frac = 0;
+        if (den != 0) {
+          // the quotient is at most 256: one reciprocal estimate is within 1 of it, one exact remainder settles which way
+          const u32 num = (u32)ad << 8;
+          u32 qv = (u32)((float)num * __builtin_amdgcn_rcpf((float)den));
+          const int rem = (int)num - (int)__umul24(qv, (u32)den);
+          qv = rem < 0 ? qv - 1 : (rem >= den ? qv + 1 : qv);
+          frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
+        }
+        out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
+        if (a.cost) cst = minsad >> a.pfshift;
+      }
+      out_prev = out;
+      cost_prev = cst;
+    }
+  }
+  flush(ye - 1);   // the segment's last row
+}
+
 // DUAL (windows that are multiples of 3): strips [0, strips3) are column-stride-3 strips in triples, the rest plain ones
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, bool DUAL>
 __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_kernel(FastArgs a) {
@@ -606,17 +988,33 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     pair = p;
     strip = inner;
   }
+  // LDS of the workgroup: per wavefront one area of WSLOT slots (staged row / exchange) + the merge area of the workgroup;
+  // single-wavefront workgroups (LDS-direct staging): two areas of WSLOT slots, 64 left-pattern dwords behind each
+  const int wvk = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  constexpr int PADS = fast_dma(NDW, NWAVES) ? 16 : 0;   // the 64 left-pattern dwords behind a staged-row area (LDS-direct staging)
   if constexpr (DUAL) {
     constexpr int NV3 = 64 - (NTERM - 1), NV1 = 64 - PW * (NTERM - 1);
+    constexpr int WS3 = FastLds<NDW, NTERM, PW, 3>::WSLOT, WS1 = FastLds<NDW, NTERM, PW, 1>::WSLOT;
     if (strip < a.strips3) {
       const int t = strip / 3;
-      sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 3>(a, t * (3 * NV3) + (strip - 3 * t), segi, pair);
+      if constexpr (fast_dma(NDW, NWAVES))
+        sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, 3>(a, fast_lds + wvk * 2 * (WS3 + PADS), fast_lds + wvk * 2 * (WS3 + PADS) + WS3 + PADS,
+                                                              reinterpret_cast<u32*>(fast_lds + NWAVES * 2 * (WS3 + PADS)), t * (3 * NV3) + (strip - 3 * t), segi, pair);
+      else sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 3>(a, t * (3 * NV3) + (strip - 3 * t), segi, pair);
     } else {
-      sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, (a.strips3 / 3) * (3 * NV3) + (strip - a.strips3) * NV1, segi, pair);
+      const int cb1 = (a.strips3 / 3) * (3 * NV3) + (strip - a.strips3) * NV1;
+      if constexpr (fast_dma(NDW, NWAVES))
+        sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, fast_lds + wvk * 2 * (WS1 + PADS), fast_lds + wvk * 2 * (WS1 + PADS) + WS1 + PADS,
+                                                              reinterpret_cast<u32*>(fast_lds + NWAVES * 2 * (WS1 + PADS)), cb1, segi, pair);
+      else sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, cb1, segi, pair);
     }
   } else {
     constexpr int NV1 = 64 - PW * (NTERM - 1);
-    sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, strip * NV1, segi, pair);
+    constexpr int WS1 = FastLds<NDW, NTERM, PW, 1>::WSLOT;
+    if constexpr (fast_dma(NDW, NWAVES))
+      sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, fast_lds + wvk * 2 * (WS1 + PADS), fast_lds + wvk * 2 * (WS1 + PADS) + WS1 + PADS,
+                                                            reinterpret_cast<u32*>(fast_lds + NWAVES * 2 * (WS1 + PADS)), strip * NV1, segi, pair);
+    else sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, strip * NV1, segi, pair);
   }
 }
 
@@ -727,7 +1125,12 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   constexpr bool DUAL = PW == 3;
   constexpr int WSLOT1 = FastLds<NDW, NTERM, PW, 1>::WSLOT, WSLOT3 = FastLds<NDW, NTERM, PW, DUAL ? 3 : 1>::WSLOT;
   constexpr int WSLOTM = WSLOT1 > WSLOT3 ? WSLOT1 : WSLOT3;
+  constexpr int NSLOT1 = FastLds<NDW, NTERM, PW, 1>::NSLOT, NSLOT3 = FastLds<NDW, NTERM, PW, DUAL ? 3 : 1>::NSLOT;
+  // per wavefront the staged-row / exchange area; then the workgroup's merge area, or -- single-wavefront workgroups with
+  // LDS-direct staging -- the second staged-row area
   size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  if (fast_dma(NDW, NWAVES))   // per wavefront two areas of WSLOT slots + 64 pattern dwords each, then the merge area
+    lds = (size_t)NWAVES * 2 * (WSLOTM + 16) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   a.bord = a.bgx = 0;
   a.bpstride = 8;
   if (border) {
@@ -777,10 +1180,13 @@ static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split
   // per row; SBM_FAST_SPLIT=0 disables)
   if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW>(a, border, s);
   if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, border, s);
-  // (two cooperating 128-disparity wavefronts at nd 256 -- SBM_FAST_MODE=2 -- run the interior kernel 7 % faster but starve
-  // the border kernel until it has drained: 1080p step 3.13 -> 3.26 ms, profiles/r03_sad_isa_budget.md)
   if (mode >= 1 && !split && a.nd <= 128) return launch_t<128, 1, NTERM, PW>(a, border, s);
-  if (mode == 2 && !split && a.nd > 192) return launch_t<128, 2, NTERM, PW>(a, border, s);
+  // Beyond 128 disparities: two cooperating 128-disparity wavefronts with LDS-direct staging (round 4: 1080p nd 256 2.58 ->
+  // 2.21 ms per step, 2160p 2.85 -> 2.43; in round 3, register-staged, this layout starved the border kernel) -- except at
+  // exactly 192, where three 64-disparity wavefronts have no masked disparities to carry (1080p nd 192: 2.09 against 2.51 ms;
+  // nd 160: 2.63 against 5.38 for the masked <64,3>; profiles/r04_dma_nd.txt). SBM_FAST_MODE=1: the 64-disparity cooperating
+  // wavefronts of rounds 1-3 everywhere (kept for small launches and as the A/B reference).
+  if (mode >= 2 && !split && a.nd > 128 && a.nd != 192) return launch_t<128, 2, NTERM, PW>(a, border, s);
   if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, border, s);
   if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, border, s);
   return launch_t<64, 4, NTERM, PW>(a, border, s);
@@ -793,7 +1199,7 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
 #if !SBM_FAST_PINGPONG
   if (!mqsad_inplace_ok(s)) return launch_sad_fast_pp(pf_l, pf_r, disp, cost, g, xa, xb, border, s);
 #endif
-  static const int mode = env_switch("SBM_FAST_MODE", SBM_FAST_PINGPONG ? 0 : 1);
+  static const int mode = env_switch("SBM_FAST_MODE", SBM_FAST_PINGPONG ? 0 : 2);
   FastArgs a;
   a.pf_l = pf_l; a.pf_r = pf_r; a.disp = disp; a.cost = g.want_cost ? reinterpret_cast<uint16_t*>(cost) : nullptr;
   a.W = g.W; a.H = g.H; a.pitch = g.pitch; a.padl = g.padl; a.plane = g.plane;
