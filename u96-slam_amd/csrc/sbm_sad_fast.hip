@@ -76,7 +76,8 @@ struct FastArgs {
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
   int pfshift;               // the planes hold (value << pfshift) + 1: every sum below is scaled by 1 << pfshift (0 or 2)
   // border jobs (sbm_sad_border_wave.h): the grid starts with nbseg x bord workgroups that carry the clamped border columns
-  int bord;                  // border workgroups per border row segment (a multiple of 8; 0: no border columns wanted)
+  int bord;                  // border workgroups per border row segment (bres x workgroups per residue; 0: no border columns wanted)
+  int bres;                  // XCD residues that have pairs: 8, or the number of pairs when that is smaller
   int bgx;                   // border wavefronts per XCD residue and segment: 2 sides x pair groups
   int bpstride;              // pair stride inside a border wavefront (8: its pairs share an XCD with their strips; 1: huge planes)
   int bseg, nbseg;           // the border jobs' own row segments: nbseg segments of bseg rows (the last one shorter)
@@ -125,7 +126,10 @@ extern __shared__ __attribute__((aligned(16))) uint4 fast_lds[];  // per wave NS
 // wavefronts per SIMD the register allocation aims at: 5 for the cooperating 64-disparity wavefronts (their two barriers
 // per row want the extra wavefront to cover the waits), 4 for a lone wavefront (no barriers: measured slower at 5),
 // 3 for the 128-disparity single-wavefront variant
-#define SBM_FAST_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(NDW > 64 ? 3 : (NWAVES > 1 ? SBM_FAST_WPE : SBM_FAST_WPE1))))
+// (two cooperating wavefronts of <= 64 disparities each only run small launches -- one pair per call -- and 48 disparities:
+// 4, i.e. 128 VGPRs, keeps their border wavefronts free of scratch -- at 96 VGPRs their spill reloads were memory round trips
+// inside the serial chain that IS the length of a one-pair SAD stage: 640x480 nd 64 w 21, one pair: 0.089 -> 0.071 ms)
+#define SBM_FAST_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(NDW > 64 ? 3 : (NWAVES > 2 ? SBM_FAST_WPE : SBM_FAST_WPE1))))
 #ifndef SBM_FAST_WPE
 #define SBM_FAST_WPE 5
 #endif
@@ -145,7 +149,13 @@ struct FastLds {
   // horizontal exchange: XCH quads at a time, XS entries per quad pair (64 lanes + the KS*(NTERM-1) halo)
   // (chunk size re-measured once the exchange had its issue priority: 8 quads per chunk -> 4: 1080p -2 %, 2160p -2 %, KITTI
   // -0.5 %; 2 quads: KITTI -1 % but +4 % / +8 % with cooperating wavefronts -- so 2 where one wavefront holds 128 disparities)
-  static constexpr int XCHMAX = NDW >= 128 ? 2 : 4;
+#ifndef SBM_FAST_XCH128   // exchange chunk (quads) of the 128-disparity wavefront / of the others (development builds compare)
+#define SBM_FAST_XCH128 2
+#endif
+#ifndef SBM_FAST_XCH64
+#define SBM_FAST_XCH64 4
+#endif
+  static constexpr int XCHMAX = NDW >= 128 ? SBM_FAST_XCH128 : SBM_FAST_XCH64;
   static constexpr int XCH = NQ < XCHMAX ? NQ : XCHMAX;
   static constexpr int XS = 64 + KS * (NTERM - 1);
   static constexpr int XSLOT = (XCH / 2) * XS + (XS * 4 + 15) / 16;
@@ -962,12 +972,13 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     // The grid starts with the border jobs (a.bord workgroups for each of their a.nbseg row segments, sbm_sad_border_wave.h):
     // they are long serial chains, so they are dispatched before any strip and finish under the strips instead of behind them.
     if ((int)blockIdx.x < a.bord * a.nbseg) {
-      // wavefront wv of border workgroup b takes border wavefront (b >> 3) * NWAVES + wv of XCD residue b & 7; no barriers in there
+      // wavefront wv of border workgroup b takes border wavefront (b / bres) * NWAVES + wv of XCD residue b % bres; no barriers in there
       using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
       const int bseg = blockIdx.x / a.bord, b = blockIdx.x - bseg * a.bord;
       const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-      const int gi = (b >> 3) * NWAVES + wv;
-      if (gi < a.bgx) sad_border_wave<(PW * NTERM) / 2, NDW * NWAVES>(a, reinterpret_cast<unsigned char*>(fast_lds) + wv * BL::BYTES, bseg, b & 7, gi);
+      const int bq = b / a.bres, x8 = b - bq * a.bres;
+      const int gi = bq * NWAVES + wv;
+      if (gi < a.bgx) sad_border_wave<(PW * NTERM) / 2, NDW * NWAVES>(a, reinterpret_cast<unsigned char*>(fast_lds) + wv * BL::BYTES, bseg, x8, gi);
       return;
     }
     const int sid = blockIdx.x - a.bord * a.nbseg;
@@ -1132,21 +1143,25 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   if (fast_dma(NDW, NWAVES))   // per wavefront two areas of WSLOT slots + 64 pattern dwords each, then the merge area
     lds = (size_t)NWAVES * 2 * (WSLOTM + 16) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   a.bord = a.bgx = 0;
+  a.bres = 8;
   a.bpstride = 8;
   if (border) {
     // border wavefronts per segment: 2 sides x ceil(n / (8 JW)) pair groups for each of the 8 XCD residues, NWAVES per workgroup
     using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
     a.bgx = 2 * ((a.npairs + 8 * BL::JW - 1) / (8 * BL::JW));
-    a.bord = 8 * ((a.bgx + NWAVES - 1) / NWAVES);
+    a.bres = std::min(8, a.npairs);   // (one pair per call: no workgroups for the seven residues without pairs)
+    a.bord = a.bres * ((a.bgx + NWAVES - 1) / NWAVES);
     if ((long)(BL::JW - 1) * 8 * a.plane + a.plane >= (1L << 31)) a.bpstride = 1;   // (JW - 1) * plane < 2^31: sad_fast_supported()
     lds = std::max(lds, (size_t)NWAVES * BL::BYTES);
     // A border wavefront is a serial chain of rows (~2 us + 0.25 us per output column and row, a quarter of that for each of
     // its w-1 priming rows -- measured alone on the chip, tools/exp/r04_bwprof.py); it must end well inside the launch, so the
-    // border jobs get their own, finer row segments: a chain of about a quarter of the launch's expected duration.
+    // border jobs get their own, finer row segments: a chain of about a fifth of the launch's expected duration (640x480 nd 64
+    // w 21 x 64 pairs, where the border columns weigh most: 10 rows per segment 0.520 ms per step, 13 rows 0.537, 6 rows 0.533 --
+    // profiles/r04_border_bseg.txt; KITTI x 64 is flat between 32 and 96 rows).
     const int rows = a.row1 - a.row0, wsz = PW * NTERM;
     const double t_kernel_us = (double)a.npairs * a.W * rows * a.nd / 3.6e12 * 1e6;
     const double t_row_us = 2.0 + 0.25 * (wsz / 2);
-    int bseg = (int)(0.25 * t_kernel_us / t_row_us - 0.25 * (wsz - 1));
+    int bseg = (int)(0.205 * t_kernel_us / t_row_us - 0.25 * (wsz - 1));
     bseg = SBM_TUNE("SBM_DEV_BSEG", bseg);
     bseg = std::max(4, std::min(bseg, rows));
     a.nbseg = (rows + bseg - 1) / bseg;
