@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 python3 "$R/tools/publish_profiles.py" --source-hash > "$OUT/source_hash.txt"   # which engine sources these counters belong to
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --prewarm-s 0"
 
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o kitti -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o kitti -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats -d "$OUT/ref640t/trace" -o ref640 -- $BENCH --w
 
 # HBM traffic of the other single-GPU workloads (ref640 = the reference's own call-site configuration)
 for wl in fhd uhd ref640; do
-  WB="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --workload $wl"
+  WB="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --prewarm-s 0 --workload $wl"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/${wl}_pmc_fetch" -o $wl -- $WB > "$OUT/bench_${wl}_fetch.json" 2> "$OUT/${wl}_fetch.err"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/${wl}_pmc_write" -o $wl -- $WB > "$OUT/bench_${wl}_write.json" 2> "$OUT/${wl}_write.err"
   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/${wl}_pmc_sq" -o $wl -- $WB > "$OUT/bench_${wl}_sq.json" 2> "$OUT/${wl}_sq.err"
