@@ -72,8 +72,11 @@ def run_sg_child(rank, local_rank, world, port, argv, timeout_s):
     scatter_gather dictionary, or {"error": ...}."""
     import subprocess
 
-    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (a launcher's own variables must not leak into the children: with TORCHELASTIC_USE_AGENT_STORE set, as torchrun does for its
+    # workers, rank 0 would not host the rendezvous store on the new port and every child would wait for it until the limit)
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "TORCH_ELASTIC_")) and k not in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, str(pathlib.Path(__file__).resolve())] + argv + ["--sg-child"]
     t0 = time.perf_counter()
     try:

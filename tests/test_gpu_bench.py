@@ -57,6 +57,25 @@ def test_two_ranks_self_launched(extra):
         assert j["ms_per_step_median"] >= j["ms_per_step_min"] > 0
 
 
+def test_two_ranks_under_torchrun_like_the_driver():
+    """The driver launches N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: the ranks are
+    torchrun workers (TORCHELASTIC_* in their environment), and the scatter/gather children they start must form their own
+    process group all the same."""
+    import socket
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "8",
+                        "--no-cpu-baseline", "--sg-timeout", "120"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SBM_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["rccl"]["ranks_seen"] == 2
+    assert "error" not in j["scatter_gather"] and j["scatter_gather"]["ms_per_step"] > 0, j["scatter_gather"]
+
+
 @pytest.mark.parametrize("fault", ["hang", "crash"])
 def test_scatter_gather_fault_cannot_lose_the_value(fault):
     """The point-to-point leg runs in child processes of the timed ranks with a wall-clock limit: a rank that hangs (or dies)
