@@ -76,10 +76,8 @@ struct FastArgs {
   int xc0, xc1;              // interior centre columns [xc0,xc1) (relative to lofs); xc0 = w/2
   int pfshift;               // the planes hold (value << pfshift) + 1: every sum below is scaled by 1 << pfshift (0 or 2)
   // border jobs (sbm_sad_border_wave.h): the grid starts with nbseg x bord workgroups that carry the clamped border columns
-  int bord;                  // border workgroups per border row segment (bres x workgroups per residue; 0: no border columns wanted)
-  int bres;                  // XCD residues that have pairs: 8, or the number of pairs when that is smaller
-  int bgx;                   // border wavefronts per XCD residue and segment: 2 sides x pair groups
-  int bpstride;              // pair stride inside a border wavefront (8: its pairs share an XCD with their strips; 1: huge planes)
+  int bord;                  // border workgroups per border row segment (0: no border columns wanted)
+  int bnw;                   // border wavefronts per border row segment: 2 sides x ceil(pairs / JW) pair groups
   int bseg, nbseg;           // the border jobs' own row segments: nbseg segments of bseg rows (the last one shorter)
 };
 
@@ -972,13 +970,12 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     // The grid starts with the border jobs (a.bord workgroups for each of their a.nbseg row segments, sbm_sad_border_wave.h):
     // they are long serial chains, so they are dispatched before any strip and finish under the strips instead of behind them.
     if ((int)blockIdx.x < a.bord * a.nbseg) {
-      // wavefront wv of border workgroup b takes border wavefront (b / bres) * NWAVES + wv of XCD residue b % bres; no barriers in there
+      // wavefront wv of border workgroup b takes border wavefront b * NWAVES + wv of its segment; no barriers in there
       using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
       const int bseg = blockIdx.x / a.bord, b = blockIdx.x - bseg * a.bord;
       const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-      const int bq = b / a.bres, x8 = b - bq * a.bres;
-      const int gi = bq * NWAVES + wv;
-      if (gi < a.bgx) sad_border_wave<(PW * NTERM) / 2, NDW * NWAVES>(a, reinterpret_cast<unsigned char*>(fast_lds) + wv * BL::BYTES, bseg, x8, gi);
+      const int wi = b * NWAVES + wv;
+      if (wi < a.bnw) sad_border_wave<(PW * NTERM) / 2, NDW * NWAVES>(a, reinterpret_cast<unsigned char*>(fast_lds) + wv * BL::BYTES, bseg, wi);
       return;
     }
     const int sid = blockIdx.x - a.bord * a.nbseg;
@@ -1142,16 +1139,12 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   if (fast_dma(NDW, NWAVES))   // per wavefront two areas of WSLOT slots + 64 pattern dwords each, then the merge area
     lds = (size_t)NWAVES * 2 * (WSLOTM + 16) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
-  a.bord = a.bgx = 0;
-  a.bres = 8;
-  a.bpstride = 8;
+  a.bord = a.bnw = 0;
   if (border) {
-    // border wavefronts per segment: 2 sides x ceil(n / (8 JW)) pair groups for each of the 8 XCD residues, NWAVES per workgroup
+    // border wavefronts per segment: 2 sides x ceil(n / JW) groups of JW consecutive pairs, NWAVES of them per workgroup
     using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
-    a.bgx = 2 * ((a.npairs + 8 * BL::JW - 1) / (8 * BL::JW));
-    a.bres = std::min(8, a.npairs);   // (one pair per call: no workgroups for the seven residues without pairs)
-    a.bord = a.bres * ((a.bgx + NWAVES - 1) / NWAVES);
-    if ((long)(BL::JW - 1) * 8 * a.plane + a.plane >= (1L << 31)) a.bpstride = 1;   // (JW - 1) * plane < 2^31: sad_fast_supported()
+    a.bnw = 2 * ((a.npairs + BL::JW - 1) / BL::JW);
+    a.bord = (a.bnw + NWAVES - 1) / NWAVES;
     lds = std::max(lds, (size_t)NWAVES * BL::BYTES);
     // A border wavefront is a serial chain of rows (~2 us + 0.25 us per output column and row, a quarter of that for each of
     // its w-1 priming rows -- measured alone on the chip, tools/exp/r04_bwprof.py); it must end well inside the launch, so the
