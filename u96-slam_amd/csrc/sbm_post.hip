@@ -801,7 +801,7 @@ hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint3
   // Two implementations. Default: band walk (runs + merge in one pass, G rows per wavefront) + seam unions, then count and
   // apply driven by the rows' compact run lists (16-bit columns: W <= 65535; 32-bit byte offsets within an image).
   // Fallback (SBM_SPECKLE_LISTS=0 or SBM_SPECKLE_BAND=0, or outside those limits): four kernels that each walk the rows.
-  // (read per call, ~0.1 us each: the GPU tests flip them between calls of one process to compare every variant with the oracle)
+  // (read per call, ~0.1 us each: the GPU tests flip them between calls of one process to compare every variant with the CPU restatement)
   const int lists_env = env_switch("SBM_SPECKLE_LISTS", 1);
   const int band_env = env_switch("SBM_SPECKLE_BAND", -1);
   const bool lists = heads && nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 30) && lists_env != 0 &&

@@ -165,7 +165,10 @@ struct FastLds {
 // ... and so do two cooperating 128-disparity wavefronts (129..256 disparities): 2 x 2 areas + the merge area still leave six
 // workgroups per CU. The 64-disparity cooperating wavefronts (5 per SIMD) keep the register-staged strip: two staged rows per
 // wavefront would cost them a workgroup per CU.
-constexpr bool fast_dma(int ndw, int nwaves) { return !SBM_FAST_PINGPONG && (nwaves == 1 || (ndw == 128 && nwaves == 2)); }
+#ifndef SBM_FAST_DMA_ALL
+#define SBM_FAST_DMA_ALL 0
+#endif
+constexpr bool fast_dma(int ndw, int nwaves) { return !SBM_FAST_PINGPONG && (SBM_FAST_DMA_ALL || nwaves == 1 || (ndw == 128 && nwaves == 2)); }
 
 // One strip of one row segment of one pair: lane i works on column cbase + CS * i (relative to lofs).
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
@@ -610,6 +613,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int d0 = wv * NDW;                              // first buffer index of this wavefront
+  const int ndl = EXACT_ND ? NDW : a.nd - d0;           // disparities of this wavefront that exist (a multiple of 16; <= 0: none)
   const int c = cbase + CS * lane;                      // this lane's column (relative to lofs): V covers c..c+2
   const int xc = c + W2;                                // centre column this lane produces
   const bool produces = lane < NV && xc >= a.xc0 && xc < a.xc1;
@@ -663,41 +667,52 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
     // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments
     // (lane stride CS * 16 bytes: 16 consecutive lanes hit 64 distinct banks for CS = 1 and for CS = 3).
     const uint4* const win_lds = buf + CS * lane;
-#pragma unroll
-    for (int q0 = 0; q0 < NQ; q0 += 16) {
-      constexpr int NM = 4;
-      uint4 ra[NM], rb[NM];
-#pragma unroll
-      for (int m = 0; m < NM; m++) {
-        ra[m] = win_lds[16 * (q0 / 4 + m)];
-        rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
+    auto quad = [&](const int q, const u32 lo, const u32 hi) {
+      const u64 win = ((u64)hi << 32) | lo;
+      if (!leave) {
+        asm("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(VB[q]) : "v"(win), "v"(pat));
+      } else {
+        const uint2 tt = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull));
+        uint2 vb = __builtin_bit_cast(uint2, VB[q]);
+        vb.x -= tt.x;                                         // no u16 lane borrows: every partial sum is exact
+        vb.y -= tt.y;
+        // (opaque: with the entering row's in-place accumulate right behind it the compiler otherwise turns the two
+        // subtractions into a 64-bit subtract with a carry chain -- three slow instructions instead of two fast ones)
+        asm("" : "+v"(vb.x), "+v"(vb.y));
+        VB[q] = __builtin_bit_cast(u64, vb);
       }
+    };
+    // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments, all issued before
+    // the first use.
+    if constexpr (EXACT_ND) {
 #pragma unroll
-      for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
-        const int q = q0 + qq;
-        // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
-        u32 lo, hi;
-        if ((qq & 1) == 0) {
-          const uint4 v = ra[qq >> 2];
-          lo = (qq & 2) ? v.z : v.x;
-          hi = (qq & 2) ? v.w : v.y;
-        } else {
-          const uint4 v = rb[(qq - 1) >> 2];
-          lo = ((qq - 1) & 2) ? v.z : v.x;
-          hi = ((qq - 1) & 2) ? v.w : v.y;
+      for (int q0 = 0; q0 < NQ; q0 += 16) {
+        constexpr int NM = 4;
+        uint4 ra[NM], rb[NM];
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+          ra[m] = win_lds[16 * (q0 / 4 + m)];
+          rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
         }
-        const u64 win = ((u64)hi << 32) | lo;
-        if (!leave) {
-          asm("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(VB[q]) : "v"(win), "v"(pat));
-        } else {
-          const uint2 tt = __builtin_bit_cast(uint2, __builtin_amdgcn_mqsad_pk_u16_u8(win, pat, 0ull));
-          uint2 vb = __builtin_bit_cast(uint2, VB[q]);
-          vb.x -= tt.x;                                         // no u16 lane borrows: every partial sum is exact
-          vb.y -= tt.y;
-          // (opaque: with the entering row's in-place accumulate right behind it the compiler otherwise turns the two
-          // subtractions into a 64-bit subtract with a carry chain -- three slow instructions instead of two fast ones)
-          asm("" : "+v"(vb.x), "+v"(vb.y));
-          VB[q] = __builtin_bit_cast(u64, vb);
+#pragma unroll
+        for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
+          // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
+          const uint4 v = (qq & 1) == 0 ? ra[qq >> 2] : rb[(qq - 1) >> 2];
+          quad(q0 + qq, (qq & 2) ? v.z : v.x, (qq & 2) ? v.w : v.y);
+        }
+      }
+    } else {
+      // Disparity counts below the wavefront's NDW (numDisparities is any multiple of 16): group by group (16 disparities), the
+      // groups that do not exist skipped outright -- wavefront-uniform branches, no masked arithmetic. (Batching the chunks that
+      // exist in full as above measured the same: profiles/r04_masked_nd.txt.)
+#pragma unroll
+      for (int g = 0; g < NQ / 4; g++) {
+        if (16 * g < ndl) {
+          const uint4 ra = win_lds[16 * g], rb = win_lds[4 + 16 * g];
+          quad(4 * g, ra.x, ra.y);
+          quad(4 * g + 1, rb.x, rb.y);
+          quad(4 * g + 2, ra.z, ra.w);
+          quad(4 * g + 3, rb.z, rb.w);
         }
       }
     }
@@ -751,6 +766,11 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
     xt[lane] = Vt;
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += XCH) {
+      if (!EXACT_ND && 4 * q0 >= ndl) {      // (a chunk of disparities that do not exist: they never win)
+#pragma unroll
+        for (int j = 2 * q0; j < 2 * (q0 + XCH); j++) S[j] = 0xffffffffu;
+        continue;
+      }
       // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
 #pragma unroll
       for (int qq = 0; qq < XCH; qq += 2) {
@@ -777,11 +797,6 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
         S[2 * (q0 + qq) + 3] = s3;
       }
       __builtin_amdgcn_wave_barrier();
-    }
-    if constexpr (!EXACT_ND) {
-#pragma unroll
-      for (int j = 0; j < NR; j++)
-        if (d0 + 2 * j >= a.nd) S[j] = 0xffffffffu;
     }
     // the texture partners are read now (the exchange area is about to receive the next entering row); the verdict crosses
     // the winner search as a wavefront-uniform mask, not in a vector register
@@ -1183,7 +1198,7 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
 template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split, hipStream_t s) {
   if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, border, s);
-  if (a.nd == 48) return launch_t<32, 2, NTERM, PW>(a, border, s);   // the masked single-wavefront variant needs 174 VGPRs
+  if (a.nd == 48 && SBM_TUNE("SBM_DEV_ND48", 0)) return launch_t<32, 2, NTERM, PW>(a, border, s);   // (rounds 1-3: two 32-disparity wavefronts)
   // one-pair calls: too few workgroups to fill the chip, so split the disparities over two wavefronts (half the serial work
   // per row; SBM_FAST_SPLIT=0 disables)
   if (a.nd <= 64 && a.nd > 32 && split) return launch_t<32, 2, NTERM, PW>(a, border, s);
