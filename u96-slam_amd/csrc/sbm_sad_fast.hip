@@ -735,13 +735,19 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   // has in flight, and stores issued at the end of a row would put their whole latency there.
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.disp + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a.cost + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
-  const int ocol = 2 * (a.lofs + xc);
-  int out_prev = 0, cost_prev = -1;
+  // (the previous row's result waits in ONE register -- disparity in the low half, cost or 0xffff = none in the high half -- and
+  // the lane's byte offset is rebuilt from CS * lane, which the staging loads keep live anyway, behind an opaque copy: two
+  // registers fewer across the row loop, which is what kept <128,2> from fitting its 168 without scratch)
+  const int ocol_u = __builtin_amdgcn_readfirstlane(2 * (a.lofs + cbase + W2));
+  u32 res_prev = 0xffff0000u;
   auto flush = [&](const int yrow) {
     if (produces && (NWAVES == 1 || (yrow % NWAVES) == wv)) {   // (this wavefront finished that row)
-      const int orow_prev = __builtin_amdgcn_readfirstlane(2 * yrow * a.W);
-      if (cost_prev >= 0) __builtin_amdgcn_raw_buffer_store_b16((short)cost_prev, rs_c, ocol, orow_prev, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)out_prev, rs_d, ocol, orow_prev, 0);
+      const int orow_prev = __builtin_amdgcn_readfirstlane(2 * yrow * a.W) + ocol_u;
+      u32 l3 = CS * lane_u;
+      asm volatile("" : "+v"(l3));
+      const int ocol = (int)(2 * l3);
+      if ((int)res_prev >= 0) __builtin_amdgcn_raw_buffer_store_b16((short)(res_prev >> 16), rs_c, ocol, orow_prev, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)res_prev, rs_d, ocol, orow_prev, 0);
     }
   };
   for (int y = ys; y < ye; y++) {
@@ -963,8 +969,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
         out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
         if (a.cost) cst = minsad >> a.pfshift;
       }
-      out_prev = out;
-      cost_prev = cst;
+      res_prev = ((u32)out & 0xffffu) | ((u32)cst << 16);   // (a cost is at most 32767; none = 0xffff)
     }
   }
   flush(ye - 1);   // the segment's last row
