@@ -61,7 +61,7 @@ def run_engine_device(pkg, oracle, params_kw, L, R):
     bm = pkg.StereoBM.create(params_kw.get("num_disparities", 64), params_kw.get("block_size", 21))
     setters = dict(prefilter_cap=bm.setPreFilterCap, min_disparity=bm.setMinDisparity, texture_threshold=bm.setTextureThreshold,
                    uniqueness_ratio=bm.setUniquenessRatio, speckle_window_size=bm.setSpeckleWindowSize,
-                   speckle_range=bm.setSpeckleRange, disp12_max_diff=bm.setDisp12MaxDiff)
+                   speckle_range=bm.setSpeckleRange, disp12_max_diff=bm.setDisp12MaxDiff, roi1=bm.setROI1, roi2=bm.setROI2)
     for k, v in params_kw.items():
         if k in setters:
             setters[k](v)
@@ -581,6 +581,33 @@ def test_rows_wider_than_4096(pkg, oracle, cfg):
     eng, ref = run_engine(pkg, oracle, kw, L, R)
     assert_stages_equal(eng, ref, kw)
     assert (eng["disp"] >= 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    # (H, W, nd, window, minDisparity, disp12MaxDiff, roi?): widths either side of the LR kernel's layout rules (two pixels per
+    # thread up to 1280 columns in blocks of 64 / 128 threads and 1..5 iterations, four pixels beyond), tolerances from 0 to "passes
+    # everything", both signs of minDisparity, ROIs that cut the checked column range
+    (24, 129, 32, 9, 0, 1, False), (24, 639, 64, 9, 0, 0, False), (20, 640, 32, 15, -8, 1, False), (20, 641, 32, 9, 5, 3, True),
+    (16, 1279, 48, 9, 0, 1, True), (16, 1280, 32, 9, -16, 2, False), (16, 1281, 32, 9, 0, 1, False), (26, 1537, 64, 15, 4, 0, True),
+    (12, 2049, 32, 9, 0, 2000, False), (12, 3073, 32, 9, -4, 1, True), (12, 4096, 48, 9, 0, 1, False), (30, 322, 16, 5, 0, 100000, False),
+])
+def test_lr_check_layouts(pkg, oracle, cfg):
+    """The left-right check on its own terms: pre-LR map, cost plane and final map against the oracle (speckle filter off, so the
+    final map is the LR kernel's output) over the widths where its thread layout changes. Filtered pixels take part in the claim
+    pass with the 0xffff cost the SAD kernels store for them: textureless bands make plenty of those."""
+    h, w, nd, wsz, mind, tol, roi = cfg
+    rng = np.random.default_rng(w * 7 + nd)
+    L, R = rand_pair(rng, h, w, shift=max(3, min(nd - 4, 9)) + min(mind, 0), noise=4)
+    L = L.copy(); R = R.copy()
+    L[:, w // 3:w // 3 + 40] = 90; R[:, w // 3:w // 3 + 40] = 90      # a textureless band: filtered pixels inside checked ranges
+    kw = dict(num_disparities=nd, block_size=wsz, min_disparity=mind, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=tol)
+    if roi:
+        kw["roi1"] = (w // 8, 1, w - w // 4, h - 2); kw["roi2"] = (w // 10, 0, w - w // 5, h - 1)
+    eng, ref = run_engine_device(pkg, oracle, kw, L[None], R[None])
+    assert_stages_equal(eng, ref, kw)
+    assert (ref["pre_lr"] != (mind - 1) * 16).mean() > 0.1     # (the case exercises the check at all)
+    assert tol >= 2000 or (ref["disp"] != ref["pre_lr"]).any()
 
 
 @pytest.mark.gpu

@@ -85,25 +85,30 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
   }
 }
 
-// Fast variant for the 16-bit cost plane (fast + border SAD kernels) and W <= 256*NPT: the row's disparities and costs are
-// loaded once, up front (NPT independent loads per lane), and the claim on a right-view column is ONE 32-bit LDS word,
+// Fast variant for the 16-bit cost plane (fast interior strips + border wavefronts) and rows of at most 4096 columns: the row's
+// disparities and costs are loaded once, up front, and the claim on a right-view column is ONE 32-bit LDS word,
 // (cost << 16) | (disparity ^ 0x8000), taken with ds_min_u32. The winner's disparity rides in the key: among the claimants of
 // one column x2 = x - round(d/16) a smaller x means a strictly smaller d, so "lowest cost, then lowest d" picks the pixel that
 // cv's "lowest cost, then lowest x" picks -- no second look-up of the winner's disparity, no copy of the row in LDS.
 // Layout: key[0] front pad (column -1), key[1 + x] column x, key[W+1], key[W+2] "no claimant" (targets outside the row read
 // here), then 64 per-lane dummy slots that absorb the claims of pixels that make none (branch-free ds_min).
-// This kernel is bound by VALU issue (about 40 instructions per pixel slot), not by memory.
+//
+// The kernel is bound by VALU issue (round 3: 50 vector instructions per pixel slot, 0.9 VALU busy), so the work went into the
+// instruction count of the common case -- a wavefront whose 128 columns lie inside every column range that matters (computed
+// columns, checked columns, valid ROI, the row itself) -- which now runs without a single range test:
+//  * the SAD kernels store cost 0xffff with every filtered pixel, so such a pixel's own key is >= 0xffff0000 = "no claimant":
+//    it may take part in the ds_min like any other (its target column x + 1 - minDisparity is inside the key array);
+//  * a filtered pixel's verdict does not matter (it stays filtered), and a valid pixel's two targets x - floor(d/16),
+//    x - ceil(d/16) are inside the row by the definition of the checked column range;
+//  * |dw - d| > tol as ONE 16-bit subtraction per target: t = (dw - d + tol) mod 2^16 > 2 tol (disparities of one map are less
+//    than 16384 apart here and tol is clamped to 16384: no aliasing), straight on the key's low half.
+// Two adjacent pixels per thread and iteration (4-byte loads / stores; rows are only 2-byte aligned: unaligned ones): half the
+// LDS bank conflicts of the four-pixel layout, a third of its unpacking.
 extern __shared__ __attribute__((aligned(16))) unsigned lr_lds32[];
 
-__device__ __forceinline__ unsigned absdiff_u32(unsigned x, unsigned y) {   // |x - y|: v_sad_u32 with a zero accumulator
-  unsigned r;
-  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y));
-  return r;
-}
-
-template <int NIT>
-__global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
-  const int BS = blockDim.x;   // 64..256 threads (a multiple of 64): narrow rows get a narrower block
+template <int NIT, int PX>   // PX = 2 or 4 adjacent pixels per thread and iteration
+__global__ void __launch_bounds__(320) lrcheck16_kernel(LrArgs a) {
+  const int BS = blockDim.x;   // 64..320 threads (a multiple of 64): narrow rows get a narrower block
   const int y = blockIdx.x;
   const size_t base = ((size_t)blockIdx.y * a.H + y) * a.W;
   int16_t* out = a.disp_out + base;
@@ -118,81 +123,100 @@ __global__ void __launch_bounds__(256) lrcheck16_kernel(LrArgs a) {
   const int INV = a.filtered;
   const int minX1 = max(max(a.mindisp + a.nd, 0), a.cx0), maxX1 = min(W + min(a.mindisp, 0), a.cx1);
   constexpr unsigned NONE = 0xffffffffu;   // real keys stay below 0xffff0000 (costs <= 65534 in this envelope)
-  // A wavefront's 256 columns of one iteration usually lie inside every column range that matters (computed columns,
-  // checked columns, valid ROI, the row itself): those iterations skip all per-pixel range tests (uniform branch).
-  const int wbase = 4 * __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  const unsigned tol2 = 2u * (unsigned)a.tol;            // (a.tol <= 16384, see launch_lrcheck)
+  const int dbias = 0x8000 - a.tol;
+  const int wbase = PX * __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
   const int lo = max(max(minX1, a.cx0), a.col0), hi = min(min(maxX1, a.cx1), min(a.col1, W));
   bool inner[NIT];
 #pragma unroll
-  for (int k = 0; k < NIT; k++) inner[k] = wbase + 4 * BS * k >= lo && wbase + 4 * BS * k + 256 <= hi;
-  // a thread owns 4 adjacent pixels per iteration: 8-byte loads / stores (rows are only 2-byte aligned: unaligned ones)
-  int dv[NIT][4];
-  unsigned kv[NIT][4];
+  for (int k = 0; k < NIT; k++) inner[k] = wbase + PX * BS * k >= lo && wbase + PX * BS * k + 64 * PX <= hi;
+  int dv[NIT][PX];
+  unsigned kv[NIT][PX];
   auto load = [&](auto inner_t, const int k) {
     constexpr bool IN = decltype(inner_t)::value;
-    const int x0 = 4 * (threadIdx.x + BS * k);
-    short dd[4] = {0, 0, 0, 0};
-    unsigned short cc[4] = {0, 0, 0, 0};
-    if (IN || x0 + 4 <= W) {
-      __builtin_memcpy(dd, dp + x0, 8);
-      __builtin_memcpy(cc, cp + x0, 8);
+    const int x0 = PX * (threadIdx.x + BS * k);
+    unsigned dd[PX / 2], cc[PX / 2];
+#pragma unroll
+    for (int j = 0; j < PX / 2; j++) dd[j] = cc[j] = 0;
+    if (IN || x0 + PX <= W) {
+      __builtin_memcpy(dd, dp + x0, 2 * PX);
+      __builtin_memcpy(cc, cp + x0, 2 * PX);
     } else {
-      for (int i = 0; x0 + i < W; i++) { dd[i] = dp[x0 + i]; cc[i] = cp[x0 + i]; }
+      for (int i = 0; x0 + i < W; i++) {
+        dd[i >> 1] |= (unsigned)(unsigned short)dp[x0 + i] << (16 * (i & 1));
+        cc[i >> 1] |= (unsigned)cp[x0 + i] << (16 * (i & 1));
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int x = x0 + i;
-      dv[k][i] = (IN || (x >= a.cx0 && x < a.cx1)) ? (int)dd[i] : INV;
-      kv[k][i] = ((unsigned)cc[i] << 16) | ((unsigned)(unsigned short)dd[i] ^ 0x8000u);
+    for (int j = 0; j < PX / 2; j++) {
+      const unsigned db = dd[j] ^ 0x80008000u;
+      dv[k][2 * j] = (int)(short)(dd[j] & 0xffffu);
+      dv[k][2 * j + 1] = (int)dd[j] >> 16;
+      kv[k][2 * j] = __builtin_amdgcn_perm(cc[j], db, 0x05040100u);       // cost.lo : biased disparity.lo
+      kv[k][2 * j + 1] = __builtin_amdgcn_perm(cc[j], db, 0x07060302u);   // cost.hi : biased disparity.hi
+    }
+    if (!IN) {
+#pragma unroll
+      for (int i = 0; i < PX; i++)
+        if (!(x0 + i >= a.cx0 && x0 + i < a.cx1)) dv[k][i] = INV;
     }
   };
   const int dummy = W + 3 + (threadIdx.x & 63);
   auto claim = [&](auto inner_t, const int k) {
     constexpr bool IN = decltype(inner_t)::value;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int x = 4 * (threadIdx.x + BS * k) + i;
+    for (int i = 0; i < PX; i++) {
+      const int x = PX * (threadIdx.x + BS * k) + i;
       const int d = dv[k][i];
       const int x2 = x - ((d + 8) >> 4);
-      const bool claims = d != INV && (IN || (x >= minX1 && x < maxX1)) && (unsigned)x2 < (unsigned)W;
-      __hip_atomic_fetch_min(&key[claims ? x2 + 1 : dummy], kv[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (IN) {
+        __hip_atomic_fetch_min(&key[x2 + 1], kv[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        const bool claims = d != INV && x >= minX1 && x < maxX1 && (unsigned)x2 < (unsigned)W;
+        __hip_atomic_fetch_min(&key[claims ? x2 + 1 : dummy], kv[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   };
   auto check = [&](auto inner_t, const int k) {
     constexpr bool IN = decltype(inner_t)::value;
-    const int x0 = 4 * (threadIdx.x + BS * k);
-    if (x0 >= W) return;
-    short res[4];
+    const int x0 = PX * (threadIdx.x + BS * k);
+    if (!IN && x0 >= W) return;
     // targets x - floor(d/16) and x - ceil(d/16): the same column or two adjacent ones -> one two-word read. A pixel that
     // is not checked, or whose floor target lies outside the row, reads "no claimant" twice (it cannot fail then: both
-    // targets must disagree); a ceil target of -1 reads the front pad. All four reads are issued before the first use, and the
-    // verdict is plain arithmetic (no short-circuit: a branch per pixel would serialise the four LDS latencies).
-    unsigned k0[4], k1[4];
+    // targets must disagree); a ceil target of -1 reads the front pad. The reads are issued before the first use, and the
+    // verdict is plain arithmetic (no short-circuit: a branch per pixel would serialise the LDS latencies).
+    unsigned k0[PX], k1[PX];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < PX; i++) {
       const int x = x0 + i;
       const int d = dv[k][i];
       const int xa = x - (d >> 4);
-      const bool checked = ((int)(d != INV) & (int)(IN || (x >= minX1 && x < maxX1)) & (int)((unsigned)xa < (unsigned)W)) != 0;
-      const int p = checked ? xa : W + 1;
+      int p = xa;
+      if (!IN) {
+        const bool checked = ((int)(d != INV) & (int)(x >= minX1 && x < maxX1) & (int)((unsigned)xa < (unsigned)W)) != 0;
+        p = checked ? xa : W + 1;
+      }
       k0[i] = key[p];            // claim of column xa-1
       k1[i] = key[p + 1];        // claim of column xa
     }
+    unsigned res[PX];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < PX; i++) {
       const int x = x0 + i;
       const int d = dv[k][i];
       const unsigned ka = k1[i], kb = (d & 15) ? k0[i] : k1[i];
-      // |winner's disparity - d| on the biased 16-bit values, one v_sad_u32 per target
-      const unsigned db16 = (unsigned)(d + 0x8000);
-      const unsigned ea = absdiff_u32(ka & 0xffffu, db16), eb = absdiff_u32(kb & 0xffffu, db16);
-      const bool bad = ((int)(max(ka, kb) < 0xffff0000u) & (int)(min(ea, eb) > (unsigned)a.tol)) != 0;
-      res[i] = (short)(((!IN && (x < a.col0 || x >= a.col1)) || bad) ? INV : d);
+      const unsigned dbt = (unsigned)(d + dbias);
+      const unsigned ta = (ka - dbt) & 0xffffu, tb = (kb - dbt) & 0xffffu;    // (winner's disparity - d + tol) mod 2^16
+      const bool bad = ((int)(max(ka, kb) < 0xffff0000u) & (int)(min(ta, tb) > tol2)) != 0;
+      res[i] = (unsigned)(((!IN && (x < a.col0 || x >= a.col1)) || bad) ? INV : d);
     }
-    if (IN || x0 + 4 <= W) {
-      __builtin_memcpy(out + x0, res, 8);
+    if (IN || x0 + PX <= W) {
+      unsigned r2[PX / 2];
+#pragma unroll
+      for (int j = 0; j < PX / 2; j++) r2[j] = __builtin_amdgcn_perm(res[2 * j + 1], res[2 * j], 0x05040100u);
+      __builtin_memcpy(out + x0, r2, 2 * PX);
     } else {
-      for (int i = 0; x0 + i < W; i++) out[x0 + i] = res[i];
+      for (int i = 0; x0 + i < W; i++) out[x0 + i] = (int16_t)res[i];
     }
   };
 #pragma unroll
@@ -222,19 +246,36 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
   a.W = g.W; a.H = g.H; a.mindisp = g.mindisp; a.nd = g.nd; a.tol = disp12_max_diff * 16; a.filtered = g.filtered;
   a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
   a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;
-  if (a.do_lr && g.cost16 && g.W <= 4096) {
+  // (the 16-bit verdict of lrcheck16_kernel: disparities of one map less than 16384 apart, tolerance clamped to that -- a larger
+  // one passes everything either way)
+  if (a.do_lr && g.cost16 && g.W <= 4096 && (g.nd + 1) * 16 <= 16384) {
+    a.tol = std::min(a.tol, 16384);
     const size_t lds16 = (size_t)(g.W + 3 + 64 + 8) * sizeof(unsigned);   // claims, pads, per-lane dummy slots
-    // 4 pixels per thread and iteration; the fewest iterations that fit a block of <= 256 threads, and then the narrowest
-    // block (a multiple of 64) that covers the row: idle wavefronts still occupy wavefront slots, and this kernel's speed is
-    // set by how many rows a CU holds at once (640 columns: 192 threads, 1242: 2 x 192; blocks wider than 256 threads
-    // measured slower at 1242, 1920 and 3840).
-    const int groups = (g.W + 3) / 4;
-    const int nit = groups <= 256 ? 1 : groups <= 512 ? 2 : 4;
-    const int bs = (((groups + nit - 1) / nit + 63) / 64) * 64;   // (one or two wavefronts per row with more iterations: no faster)
-    if (nit == 1) hipLaunchKernelGGL(lrcheck16_kernel<1>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
-    else if (nit == 2) hipLaunchKernelGGL(lrcheck16_kernel<2>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
-    else hipLaunchKernelGGL(lrcheck16_kernel<4>, dim3(g.H, g.n), dim3(bs), lds16, s, a);
-    return hipGetLastError();
+    // PX pixels per thread and iteration, blocks of at most BSMAX threads, the fewest iterations that cover the row with them and
+    // then the narrowest block (a multiple of 64) that does. Measured (profiles/r04_lr_sweep.txt): what counts is how few idle
+    // pixel slots the cover leaves and, for rows up to ~1300 columns, few wavefronts per row -- 2 pixels x 5 iterations x one
+    // (640 columns) or two (1242) wavefronts; wider rows do best with 4 pixels x 256 threads x 2..4 iterations.
+    int px = g.W <= 1280 ? 2 : 4;
+    int bsmax = px == 4 ? 256 : (g.W <= 640 ? 64 : 128);
+    if (SBM_TUNE("SBM_DEV_LR_PX", 0)) px = SBM_TUNE("SBM_DEV_LR_PX", 0) == 2 ? 2 : 4;
+    if (SBM_TUNE("SBM_DEV_LR_BS", 0)) bsmax = std::max(64, std::min(320, SBM_TUNE("SBM_DEV_LR_BS", 0) / 64 * 64));
+    const int groups = (g.W + px - 1) / px;
+    const int nit = (groups + bsmax - 1) / bsmax;
+    const int bs = (((groups + nit - 1) / nit + 63) / 64) * 64;
+    const dim3 grid(g.H, g.n), block(bs);
+    bool launched = true;
+#define SBM_LR_CASE(N, P) case N * 8 + P: hipLaunchKernelGGL((lrcheck16_kernel<N, P>), grid, block, lds16, s, a); break;
+    switch (nit * 8 + px) {
+      SBM_LR_CASE(1, 2) SBM_LR_CASE(2, 2) SBM_LR_CASE(3, 2) SBM_LR_CASE(4, 2) SBM_LR_CASE(5, 2)   // up to 1280 columns
+      SBM_LR_CASE(2, 4) SBM_LR_CASE(3, 4) SBM_LR_CASE(4, 4)                                       // 1281 .. 4096 columns
+#ifdef SBM_DEV
+      SBM_LR_CASE(1, 4) SBM_LR_CASE(5, 4) SBM_LR_CASE(6, 4) SBM_LR_CASE(7, 4) SBM_LR_CASE(8, 4) SBM_LR_CASE(6, 2) SBM_LR_CASE(7, 2) SBM_LR_CASE(8, 2)
+#endif
+      default: launched = false;
+    }
+#undef SBM_LR_CASE
+    if (launched) return hipGetLastError();
+    a.tol = disp12_max_diff * 16;   // (no such instantiation: the generic kernel below)
   }
   size_t lds = a.do_lr ? (size_t)g.W * sizeof(unsigned long long) : 0;
   hipLaunchKernelGGL(lrcheck_kernel, dim3(g.H, g.n), dim3(256), lds, s, a);

@@ -552,7 +552,7 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
         ok = ok && acc_lo == exp_lo && acc_hi == exp_hi;
       }
       if (produces) {
-        int out = a.filtered;
+        int out = a.filtered, cst = 0xffff;   // (a filtered pixel's cost reads 0xffff: the LR kernel relies on it, sbm_post.hip)
         if (ok) {
           const int ad = pp > nn ? pp - nn : nn - pp;
           const int den = pp + nn - 2 * minsad + ad;
@@ -567,8 +567,9 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
             frac = pp >= nn ? (int)qv : -(int)qv;          // C division truncates toward zero
           }
           out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
-          if (a.cost) __builtin_amdgcn_raw_buffer_store_b16((short)(minsad >> a.pfshift), rs_c, ocol, orow, 0);
+          cst = minsad >> a.pfshift;
         }
+        if (a.cost) __builtin_amdgcn_raw_buffer_store_b16((short)cst, rs_c, ocol, orow, 0);
         __builtin_amdgcn_raw_buffer_store_b16((short)out, rs_d, ocol, orow, 0);
       }
     }
@@ -735,7 +736,8 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   // has in flight, and stores issued at the end of a row would put their whole latency there.
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.disp + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a.cost + (size_t)pair * a.W * a.H, 0, 0x7fffffff, 0x00020000);
-  // (the previous row's result waits in ONE register -- disparity in the low half, cost or 0xffff = none in the high half -- and
+  // (the previous row's result waits in ONE register -- disparity in the low half, cost in the high half, 0xffff for a filtered
+  // pixel: that is also what the cost plane holds there, the LR kernel relies on it -- and
   // the lane's byte offset is rebuilt from CS * lane, which the staging loads keep live anyway, behind an opaque copy: two
   // registers fewer across the row loop, which is what kept <128,2> from fitting its 168 without scratch)
   const int ocol_u = __builtin_amdgcn_readfirstlane(2 * (a.lofs + cbase + W2));
@@ -746,7 +748,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
       u32 l3 = CS * lane_u;
       asm volatile("" : "+v"(l3));
       const int ocol = (int)(2 * l3);
-      if ((int)res_prev >= 0) __builtin_amdgcn_raw_buffer_store_b16((short)(res_prev >> 16), rs_c, ocol, orow_prev, 0);
+      if (a.cost) __builtin_amdgcn_raw_buffer_store_b16((short)(res_prev >> 16), rs_c, ocol, orow_prev, 0);
       __builtin_amdgcn_raw_buffer_store_b16((short)res_prev, rs_d, ocol, orow_prev, 0);
     }
   };
@@ -969,7 +971,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
         out = ((a.nd - mind - 1 + a.mindisp) * 256 + frac + 15) >> 4;
         if (a.cost) cst = minsad >> a.pfshift;
       }
-      res_prev = ((u32)out & 0xffffu) | ((u32)cst << 16);   // (a cost is at most 32767; none = 0xffff)
+      res_prev = ((u32)out & 0xffffu) | ((u32)cst << 16);   // (a cost is at most 65534; filtered = 0xffff)
     }
   }
   flush(ye - 1);   // the segment's last row
