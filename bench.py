@@ -545,7 +545,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
                     "stage_ms": {k: round(v, 4) for k, v in prof.items()},
-                    "stage_ms_from": "HIP events on every 4th timed step (an instrumented step runs ~25 us longer than the others)"
+                    "stage_ms_from": "HIP events on every 4th timed step (an instrumented step runs ~20 us longer than the others)"
                     if (not args.no_profile and args.steps >= 8) else "HIP events on every timed step", **pmc_extra}
 
         # the roof that does bound the kernel (SURVEY.md 8d "algorithmic ops"): vector lane-operations per second. Peak = 256 CUs x

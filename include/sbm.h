@@ -172,11 +172,11 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
  * enabled = 1: every sbm_compute_device call synchronises and sbm_get_profile returns the LAST call's times;
  * enabled = 2: events are recorded without synchronising (use inside a timed region) and sbm_get_profile
  *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
- * enabled = 3: as 2, but only every 4th call is instrumented (the six event records cost ~25 us per call at the bench size;
+ * enabled = 3: as 2, but only every 4th call is instrumented (the five event records cost ~20 us per call at the bench size;
  *              sampling keeps a timed region close to the un-instrumented rate).
  * names: "prefilter", "sad" (the SAD/WTA kernel of the call: the interior kernel, or the generic kernel when the fast path is
- * off -- sbm_last_kernel_name() says which), "border" (what is left of the border-column kernel after the interior kernel
- * has finished; ~0 when the fast path is off), "lrcheck", "speckle", "total". */
+ * off -- sbm_last_kernel_name() says which), "lrcheck", "speckle", "total"; "border" is still accepted and reads 0 (the
+ * clamped border columns have been wavefronts of the SAD launch since round 4: there is no second kernel to time). */
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
 

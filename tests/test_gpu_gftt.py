@@ -26,7 +26,11 @@ def test_gftt_map_and_max_register(pkg, oracle, golden):
     assert eig[3].max() > 30000
 
 
-@pytest.mark.parametrize("W,H", [(3, 5), (65, 17), (130, 33), (1023, 511)])
+@pytest.mark.parametrize("W,H", [(3, 5), (65, 17), (130, 33), (1023, 511),
+                                 # the two-columns-per-lane kernel (W >= 8): widths around its 126-column strips, odd and even
+                                 # (the last Sobel column is a lane's first or second column), heights around its 3-row trips
+                                 (7, 9), (8, 7), (9, 8), (125, 12), (126, 20), (127, 21), (128, 9), (252, 12), (253, 40), (254, 11),
+                                 (379, 6), (640, 65), (1000, 130)])
 def test_gftt_odd_sizes(pkg, oracle, W, H):
     import torch
 

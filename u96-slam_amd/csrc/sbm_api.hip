@@ -410,18 +410,20 @@ static inline void mark(sbm_handle* h, int i) {
 static void collect_profile(sbm_handle* h) {
   unsigned nrec = std::min<unsigned>(h->calls, sbm_handle::kRing), first = 0;
   if (h->profiling == 1 && h->calls > 0) { first = (h->calls - 1) % sbm_handle::kRing; nrec = 1; }
-  float acc[5] = {0, 0, 0, 0, 0}, tot = 0.f;
+  // events 0..5 with 3 unused (it used to close the border kernel's side stream; one launch carries those columns now)
+  static const int kFrom[4] = {0, 1, 2, 4}, kTo[4] = {1, 2, 4, 5};
+  float acc[4] = {0, 0, 0, 0}, tot = 0.f;
   for (unsigned r = first; r < first + nrec; r++) {
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 4; i++) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, h->ev[r][i], h->ev[r][i + 1]) == hipSuccess) acc[i] += ms;
+      if (hipEventElapsedTime(&ms, h->ev[r][kFrom[i]], h->ev[r][kTo[i]]) == hipSuccess) acc[i] += ms;
     }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev[r][0], h->ev[r][5]) == hipSuccess) tot += ms;
   }
   const float inv = nrec ? 1.f / nrec : 0.f;
-  h->ms_prefilter = acc[0] * inv; h->ms_sad = acc[1] * inv; h->ms_border = acc[2] * inv; h->ms_lr = acc[3] * inv;
-  h->ms_speckle = acc[4] * inv; h->ms_total = tot * inv;
+  h->ms_prefilter = acc[0] * inv; h->ms_sad = acc[1] * inv; h->ms_border = 0.f; h->ms_lr = acc[2] * inv;
+  h->ms_speckle = acc[3] * inv; h->ms_total = tot * inv;
 }
 
 int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_right, int width, int height,
@@ -511,11 +513,8 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
       HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_generic_kernel");
     }
-    mark(h, 2);
-  } else {
-    mark(h, 2);
   }
-  mark(h, 3);
+  mark(h, 2);
   HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
   mark(h, 4);
   if (speckle)

@@ -542,7 +542,7 @@ class StereoBM:
 
     def profile(self):
         out = {}
-        for k in ("prefilter", "sad", "border", "lrcheck", "speckle", "total"):
+        for k in ("prefilter", "sad", "lrcheck", "speckle", "total"):
             v = ctypes.c_float()
             _check(self._L.sbm_get_profile(self._h, k.encode(), ctypes.byref(v)), self._h)
             out[k] = v.value
