@@ -168,6 +168,16 @@ struct FastLds {
 #ifndef SBM_FAST_DMA_ALL
 #define SBM_FAST_DMA_ALL 0
 #endif
+// LDS-direct staging granularity: 1 = single-wavefront workgroups use dword loads into a 4x-expanded layout (slot p = bytes
+// p..p+3) read back with ds_read2_b32 (2: every LDS-direct strip does); 0 = 16-byte loads into the 16x-expanded layout read
+// back with ds_read_b128. A byte-misaligned 16-byte LDS-direct load costs the texture path 64 CU-cycles per wavefront-
+// instruction, a dword one 16 (tools/ubench/lds_dma_rate.hip, profiles/r04_lds_dma_rate.txt): with 10 loads per wavefront-row
+// the 16-byte form kept that path 80 % busy at KITTI size and WAS the bound at 64 disparities and below (KITTI x64 nd 32:
+// 0.733 -> 0.466 ms per step, nd 64: 0.721 -> 0.603, nd 128: 0.960 -> 0.944; 640x480 nd 64 w 21: 0.514 -> 0.489). The two
+// cooperating 128-disparity wavefronts keep the 16-byte form: with twice the window-read instructions they measured +0.4 %.
+#ifndef SBM_FAST_DMA4
+#define SBM_FAST_DMA4 1
+#endif
 constexpr bool fast_dma(int ndw, int nwaves) { return !SBM_FAST_PINGPONG && (SBM_FAST_DMA_ALL || nwaves == 1 || (ndw == 128 && nwaves == 2)); }
 
 // One strip of one row segment of one pair: lane i works on column cbase + CS * i (relative to lofs).
@@ -610,6 +620,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   constexpr int NV = 64 - KS * (NTERM - 1);   // lanes that produce an output
   constexpr int XCH = L::XCH, XS = L::XS;
   constexpr int WSLOT = L::WSLOT;
+  constexpr bool DMA4 = SBM_FAST_DMA4 == 2 || (SBM_FAST_DMA4 == 1 && NWAVES == 1);   // staging granularity, see SBM_FAST_DMA4
 
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -647,8 +658,12 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   auto stage = [&](const int y, uint4* const buf) {
     const int rowoff = __builtin_amdgcn_readfirstlane(y * a.pitch);
 #pragma unroll
-    for (int it = 0; it < NIT; it++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(buf + 64 * it), 16, (int)lane_u, rowoff + 64 * it, 0, 0);
+    for (int it = 0; it < NIT; it++) {
+      if constexpr (DMA4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(reinterpret_cast<u32*>(buf) + 64 * it), 4, (int)lane_u, rowoff + 64 * it, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(buf + 64 * it), 16, (int)lane_u, rowoff + 64 * it, 0, 0);
+    }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lds_vptr)pat_of(buf), 4, (int)(CS * lane_u), rowoff, 0, 0);
   };
   auto landed = [] {        // everything this wavefront has in flight has landed (LDS-direct loads count in vmcnt)
@@ -683,37 +698,64 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
         VB[q] = __builtin_bit_cast(u64, vb);
       }
     };
-    // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments, all issued before
-    // the first use.
-    if constexpr (EXACT_ND) {
-#pragma unroll
-      for (int q0 = 0; q0 < NQ; q0 += 16) {
-        constexpr int NM = 4;
-        uint4 ra[NM], rb[NM];
-#pragma unroll
-        for (int m = 0; m < NM; m++) {
-          ra[m] = win_lds[16 * (q0 / 4 + m)];
-          rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
+    if constexpr (DMA4) {
+      // 4x-expanded staging (dword slot p = bytes p..p+3): the window of quad q is the dword pair (4q, 4q + 4) behind the lane's
+      // slot -- one ds_read2_b32 each (lane stride CS dwords: conflict-free for CS = 1 and 3), 16 issued before the first use
+      const u32* const win4 = reinterpret_cast<const u32*>(buf) + CS * lane;
+      if constexpr (EXACT_ND) {
+  #pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += 16) {
+          u32 lo[16], hi[16];
+  #pragma unroll
+          for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) { lo[qq] = win4[4 * (q0 + qq)]; hi[qq] = win4[4 * (q0 + qq) + 4]; }
+  #pragma unroll
+          for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) quad(q0 + qq, lo[qq], hi[qq]);
         }
-#pragma unroll
-        for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
-          // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
-          const uint4 v = (qq & 1) == 0 ? ra[qq >> 2] : rb[(qq - 1) >> 2];
-          quad(q0 + qq, (qq & 2) ? v.z : v.x, (qq & 2) ? v.w : v.y);
+      } else {
+  #pragma unroll
+        for (int g = 0; g < NQ / 4; g++) {
+          if (16 * g < ndl) {
+            u32 lo[4], hi[4];
+  #pragma unroll
+            for (int k = 0; k < 4; k++) { lo[k] = win4[4 * (4 * g + k)]; hi[k] = win4[4 * (4 * g + k) + 4]; }
+  #pragma unroll
+            for (int k = 0; k < 4; k++) quad(4 * g + k, lo[k], hi[k]);
+          }
         }
       }
     } else {
-      // Disparity counts below the wavefront's NDW (numDisparities is any multiple of 16): group by group (16 disparities), the
-      // groups that do not exist skipped outright -- wavefront-uniform branches, no masked arithmetic. (Batching the chunks that
-      // exist in full as above measured the same: profiles/r04_masked_nd.txt.)
-#pragma unroll
-      for (int g = 0; g < NQ / 4; g++) {
-        if (16 * g < ndl) {
-          const uint4 ra = win_lds[16 * g], rb = win_lds[4 + 16 * g];
-          quad(4 * g, ra.x, ra.y);
-          quad(4 * g + 1, rb.x, rb.y);
-          quad(4 * g + 2, ra.z, ra.w);
-          quad(4 * g + 3, rb.z, rb.w);
+      // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments, all issued before
+      // the first use.
+      if constexpr (EXACT_ND) {
+  #pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += 16) {
+          constexpr int NM = 4;
+          uint4 ra[NM], rb[NM];
+  #pragma unroll
+          for (int m = 0; m < NM; m++) {
+            ra[m] = win_lds[16 * (q0 / 4 + m)];
+            rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
+          }
+  #pragma unroll
+          for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
+            // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
+            const uint4 v = (qq & 1) == 0 ? ra[qq >> 2] : rb[(qq - 1) >> 2];
+            quad(q0 + qq, (qq & 2) ? v.z : v.x, (qq & 2) ? v.w : v.y);
+          }
+        }
+      } else {
+        // Disparity counts below the wavefront's NDW (numDisparities is any multiple of 16): group by group (16 disparities), the
+        // groups that do not exist skipped outright -- wavefront-uniform branches, no masked arithmetic. (Batching the chunks that
+        // exist in full as above measured the same: profiles/r04_masked_nd.txt.)
+  #pragma unroll
+        for (int g = 0; g < NQ / 4; g++) {
+          if (16 * g < ndl) {
+            const uint4 ra = win_lds[16 * g], rb = win_lds[4 + 16 * g];
+            quad(4 * g, ra.x, ra.y);
+            quad(4 * g + 1, rb.x, rb.y);
+            quad(4 * g + 2, ra.z, ra.w);
+            quad(4 * g + 3, rb.z, rb.w);
+          }
         }
       }
     }
