@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "sbm_common.h"
 
@@ -44,6 +45,9 @@
 #endif
 #ifndef SBM_FAST_PINGPONG
 #define SBM_FAST_PINGPONG 0
+#endif
+#ifndef SBM_FAST_HPLAN5   // terms per T of a 5-term window (2: T = V + V', window = T + T'' + V''''; 1: direct)
+#define SBM_FAST_HPLAN5 1
 #endif
 
 #if SBM_FAST_PINGPONG   // second build of this file (sbm_sad_fast_pp.hip): same kernels with two accumulator arrays
@@ -160,6 +164,28 @@ struct FastLds {
   static constexpr int WSLOT = NSLOT > XSLOT ? NSLOT : XSLOT;
   static_assert(CS == 1 || (CS == 3 && PW == 3), "column stride 3 goes with 3-column sums");
 };
+
+// Plan of the horizontal window sum (LDS-direct strips). The window is NTERM vertical sums V at lane distance KS. Summing
+// them directly costs NTERM - 1 partner reads and (NTERM - 1) / 2 three-operand adds per register; in LEVELS -- T = S1
+// consecutive V, U = S2 consecutive T, every level published to its own exchange area and read back shifted -- the window is
+// NU U's + NTT T's + NVV V's (greedy, left to right): w 21 = T(0) + T(3) + V(6) with T = 3 V: 2 + 2 reads and 2 adds instead of
+// 6 and 3; w 19 (1-column sums) = U(0) + U(9) + V(18): 2 + 2 + 2 reads, 3 adds instead of 18 and 9. The exchange writes
+// double or triple; the LDS pipe has the room (round 4 left it 0.19 busy), the vector unit has none.
+#ifndef SBM_FAST_HPLAN   // 0: direct sums everywhere (the round-4 exchange; development builds compare)
+#define SBM_FAST_HPLAN 1
+#endif
+template <int NTERM, int PW>
+struct HPlan {
+  static constexpr int S1 = !SBM_FAST_HPLAN ? 1 : (NTERM >= 7 ? 3 : (NTERM >= 5 ? SBM_FAST_HPLAN5 : 1));
+  static constexpr int S2 = SBM_FAST_HPLAN && NTERM >= 19 ? 3 : 1;
+  static constexpr int SP2 = S1 * S2;                                  // V's under one U
+  static constexpr int NU = S2 > 1 ? NTERM / SP2 : 0;
+  static constexpr int NTT = S1 > 1 ? (NTERM - NU * SP2) / S1 : 0;
+  static constexpr int NVV = NTERM - NU * SP2 - NTT * S1;
+  static constexpr bool PUB1 = S1 > 1 && (S2 > 1 || NTT + (NU > 0) >= 2);   // T is read by other lanes
+  static constexpr bool PUB2 = NU >= 2;                                   // U is read by other lanes
+  static constexpr int NLEV = 1 + PUB1 + PUB2;                            // exchange areas
+};
 // Single-wavefront workgroups stage their rows with LDS-direct loads (see sad_fast_strip): two staged rows per wavefront
 // (entering / leaving), the first one doubling as the exchange area.
 // ... and so do two cooperating 128-disparity wavefronts (129..256 disparities): 2 x 2 areas + the merge area still leave six
@@ -179,6 +205,30 @@ struct FastLds {
 #define SBM_FAST_DMA4 1
 #endif
 constexpr bool fast_dma(int ndw, int nwaves) { return !SBM_FAST_PINGPONG && (SBM_FAST_DMA_ALL || nwaves == 1 || (ndw == 128 && nwaves == 2)); }
+
+// Neighbour sums S[mind - 1], S[mind + 1] of the LDS-direct strips: 0 = byte-permute selection tree over the registers
+// (NR - 1 v_perm_b32 + selectors: 406 of 3 850 SIMD-cycles per wavefront-row at 128 disparities, profiles/r05_sad_isa_budget.md),
+// 1 = S goes to LDS in NPH phases (NR / 4 ds_write_b128 in all) and every lane fetches its two entries with ds_read_u16.
+#ifndef SBM_FAST_NBR
+#define SBM_FAST_NBR 1
+#endif
+// LDS of one wavefront of an LDS-direct strip, in bytes: two staged-row areas (the first doubles as exchange level 0; 64
+// left-pattern dwords behind each), the further exchange levels of the plan, the S dump of the neighbour look-up.
+template <int NDW, int NWAVES, int NTERM, int PW, int CS>
+struct DmaLds {
+  using L = FastLds<NDW, NTERM, PW, CS>;
+  using P = HPlan<NTERM, PW>;
+  static constexpr bool DMA4 = SBM_FAST_DMA4 == 2 || (SBM_FAST_DMA4 == 1 && NWAVES == 1);
+  static constexpr int XCH = DMA4 && L::NQ >= 2 ? 2 : L::XCH;                 // exchange chunk (quads)
+  static constexpr int STAGE_B = DMA4 ? L::NSLOT * 4 : L::NSLOT * 16;       // one staged right row piece
+  static constexpr int XLEV_B = ((XCH / 2) * L::XS + (L::XS * 4 + 15) / 16) * 16;   // one exchange level: quad entries + texture column
+  static constexpr int PAT_OFS = STAGE_B > XLEV_B ? STAGE_B : XLEV_B;       // the left patterns of a staged row
+  static constexpr int AREA_B = PAT_OFS + 256;
+  static constexpr bool NBR = SBM_FAST_NBR && NWAVES == 1 && NDW >= 64;
+  static constexpr int NPH = NDW >= 128 ? 2 : 1;                             // dump phases (NDW / NPH disparities each)
+  static constexpr int DUMP_B = NBR ? (NDW / 2 / NPH) * 256 : 0;                 // [register][lane] dwords of one phase
+  static constexpr int WAVE_B = 2 * AREA_B + (P::NLEV - 1) * XLEV_B + DUMP_B;
+};
 
 // One strip of one row segment of one pair: lane i works on column cbase + CS * i (relative to lofs).
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
@@ -607,9 +657,13 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
 // while LDS-direct loads into the other are in flight (the compiler makes every LDS access that MAY alias a pending
 // LDS-direct load wait for it).
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
-__device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __restrict__ const b0, uint4* __restrict__ const b1, u32* __restrict__ const xkey,
+__device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned char* __restrict__ const b0c, unsigned char* __restrict__ const b1c,
+                                                   unsigned char* __restrict__ const xl1c, unsigned char* __restrict__ const xl2c,
+                                                   unsigned char* __restrict__ const dumpc, u32* __restrict__ const xkey,
                                                    const int cbase, const int segi, const int pair) {
   using L = FastLds<NDW, NTERM, PW, CS>;
+  using D = DmaLds<NDW, NWAVES, NTERM, PW, CS>;
+  using P = HPlan<NTERM, PW>;
   typedef __attribute__((address_space(3))) void* lds_vptr;
   constexpr int NQ = NDW / 4;           // disparity quads of this wavefront (one u64 accumulator each)
   constexpr int NR = NDW / 2;           // packed pair registers
@@ -618,9 +672,8 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   constexpr int WSZ = PW * NTERM, W2 = WSZ / 2;
   constexpr int KS = L::KS;
   constexpr int NV = 64 - KS * (NTERM - 1);   // lanes that produce an output
-  constexpr int XCH = L::XCH, XS = L::XS;
-  constexpr int WSLOT = L::WSLOT;
-  constexpr bool DMA4 = SBM_FAST_DMA4 == 2 || (SBM_FAST_DMA4 == 1 && NWAVES == 1);   // staging granularity, see SBM_FAST_DMA4
+  constexpr int XCH = D::XCH, XS = L::XS;
+  constexpr bool DMA4 = D::DMA4;        // staging granularity, see SBM_FAST_DMA4
 
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -639,9 +692,14 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   // raw buffer descriptors over the rest of this pair's planes (rows of one pair are < 2^31 bytes apart)
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pl), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pr), 0, 0x7fffffff, 0x00020000);
-  // b0 after its staged row has been consumed: the exchange area of the horizontal window
-  uint4* const xq = b0;                                                 // [XCH/2 quad pairs][XS lanes], 8 x u16 each
-  u32* const xt = reinterpret_cast<u32*>(xq + (XCH / 2) * XS);          // [XS] texture column sums
+  uint4* const b0 = reinterpret_cast<uint4*>(b0c);
+  uint4* const b1 = reinterpret_cast<uint4*>(b1c);
+  // exchange areas of the horizontal window, one per level of the plan: [XCH/2 quad pairs][XS lanes] 8 x u16, then [XS]
+  // texture column sums. Level 0 is b0 after its staged row has been consumed.
+  uint4* const xq0 = b0;
+  uint4* const xq1 = reinterpret_cast<uint4*>(xl1c);
+  uint4* const xq2 = reinterpret_cast<uint4*>(xl2c);
+  auto xt_of = [](uint4* const xq) { return reinterpret_cast<u32*>(xq + (XCH / 2) * XS); };
   const u32 capw = (u32)a.capb * 0x01010101u;
 
   // vertical sums, packed 4 x u16 per quad (low dword = indices 4q, 4q+1, high dword = 4q+2, 4q+3), accumulated in place
@@ -653,8 +711,8 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
 
   // buffer_load_dwordx4 ... lds: lane i of load `it` writes its 16 source bytes (row piece bytes 64 it + i .. + 15: a byte-
   // granular source address is fine, tools/ubench/lds_dma.hip) to LDS slot 64 it + i -- the 16x-expanded layout without a
-  // staging register or a ds_write. The lanes' left patterns follow as 64 dwords behind the area's WSLOT slots (pat_of()).
-  auto pat_of = [](uint4* const buf) { return reinterpret_cast<u32*>(buf + WSLOT); };
+  // staging register or a ds_write. The lanes' left patterns follow as 64 dwords at D::PAT_OFS (pat_of()).
+  auto pat_of = [](uint4* const buf) { return reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(buf) + D::PAT_OFS); };
   auto stage = [&](const int y, uint4* const buf) {
     const int rowoff = __builtin_amdgcn_readfirstlane(y * a.pitch);
 #pragma unroll
@@ -673,6 +731,10 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
   };
   auto reads_done = [] {    // every LDS read of this wavefront has returned (lgkmcnt = 0): an area may be overwritten
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto published = [] {     // this wavefront's LDS writes are ordered before its following reads of other lanes' entries
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
   // the staged row in `buf` enters (leave == false) or leaves the vertical sums
@@ -811,52 +873,92 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
     // issue priority while this wavefront is in its exchange (a chain of LDS round trips with a few adds behind each): see
     // sad_fast_strip
     __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
-    // ---- horizontal window across lanes: S(c + w/2) = sum_k V(c + PW k) through LDS ------------------------------------
+    // ---- horizontal window across lanes: S(c + w/2) = sum_k V(c + PW k) through LDS, level by level (HPlan) ---------------
+    // A chunk of XCH quads at a time: publish V, read the S1 - 1 partners of T, publish T, ... ; the last level adds the
+    // remaining T's and V's. Lanes >= NV read entries nobody wrote (halo): their sums are garbage and never stored. The
+    // texture column sum takes the same route as a 32-bit column of its own, with the first chunk.
     u32 S[NR];
-    xt[lane] = Vt;
+    unsigned long long tex_ok = 0;
+    auto add4 = [](u32 (&acc)[4], const uint4 r) { acc[0] += r.x; acc[1] += r.y; acc[2] += r.z; acc[3] += r.w; };   // packed u16 pairs: no carries, every sum stays below 65535
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += XCH) {
+      const bool tex_now = q0 == 0;          // (the first chunk always exists: ndl >= 16)
       if (!EXACT_ND && 4 * q0 >= ndl) {      // (a chunk of disparities that do not exist: they never win)
 #pragma unroll
         for (int j = 2 * q0; j < 2 * (q0 + XCH); j++) S[j] = 0xffffffffu;
         continue;
       }
-      // two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
+      u32 A[XCH / 2][4];
+      u32 tA = Vt;
+      // level 0: two quads (16 bytes) per LDS entry: ds_write_b128 / ds_read_b128 at lane stride 16 B
 #pragma unroll
-      for (int qq = 0; qq < XCH; qq += 2) {
-        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
-        xq[(qq / 2) * XS + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      for (int e = 0; e < XCH / 2; e++) {
+        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + 2 * e]), v1 = __builtin_bit_cast(uint2, VB[q0 + 2 * e + 1]);
+        A[e][0] = v0.x; A[e][1] = v0.y; A[e][2] = v1.x; A[e][3] = v1.y;
+        xq0[e * XS + lane] = make_uint4(v0.x, v0.y, v1.x, v1.y);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      if (tex_now) xt_of(xq0)[lane] = Vt;
+      published();
+      if constexpr (P::S1 > 1) {            // T = S1 consecutive V
 #pragma unroll
-      for (int qq = 0; qq < XCH; qq += 2) {
-        const uint2 v0 = __builtin_bit_cast(uint2, VB[q0 + qq]), v1 = __builtin_bit_cast(uint2, VB[q0 + qq + 1]);
-        u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
+        for (int e = 0; e < XCH / 2; e++)
 #pragma unroll
-        for (int k = 1; k < NTERM; k++) {
-          const uint4 r = xq[(qq / 2) * XS + lane + KS * k];
-          s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
-          s1 += r.y;
-          s2 += r.z;
-          s3 += r.w;
+          for (int k = 1; k < P::S1; k++) add4(A[e], xq0[e * XS + lane + KS * k]);
+        if (tex_now)
+#pragma unroll
+          for (int k = 1; k < P::S1; k++) tA += xt_of(xq0)[lane + KS * k];
+        if constexpr (P::PUB1) {
+#pragma unroll
+          for (int e = 0; e < XCH / 2; e++) xq1[e * XS + lane] = make_uint4(A[e][0], A[e][1], A[e][2], A[e][3]);
+          if (tex_now) xt_of(xq1)[lane] = tA;
+          published();
         }
-        S[2 * (q0 + qq)] = s0;
-        S[2 * (q0 + qq) + 1] = s1;
-        S[2 * (q0 + qq) + 2] = s2;
-        S[2 * (q0 + qq) + 3] = s3;
       }
+      if constexpr (P::S2 > 1) {            // U = S2 consecutive T
+#pragma unroll
+        for (int e = 0; e < XCH / 2; e++)
+#pragma unroll
+          for (int k = 1; k < P::S2; k++) add4(A[e], xq1[e * XS + lane + KS * P::S1 * k]);
+        if (tex_now)
+#pragma unroll
+          for (int k = 1; k < P::S2; k++) tA += xt_of(xq1)[lane + KS * P::S1 * k];
+        if constexpr (P::PUB2) {
+#pragma unroll
+          for (int e = 0; e < XCH / 2; e++) xq2[e * XS + lane] = make_uint4(A[e][0], A[e][1], A[e][2], A[e][3]);
+          if (tex_now) xt_of(xq2)[lane] = tA;
+          published();
+        }
+      }
+      // the window: NU U's, then NTT T's, then NVV V's, left to right; the first term is this lane's own (in A)
+      {
+        constexpr int OT = P::NU * P::SP2, OV = OT + P::NTT * P::S1;   // first T / first V behind the U's / T's
+#pragma unroll
+        for (int e = 0; e < XCH / 2; e++) {
+#pragma unroll
+          for (int u = 1; u < P::NU; u++) add4(A[e], xq2[e * XS + lane + KS * P::SP2 * u]);
+#pragma unroll
+          for (int t = (P::NU > 0 ? 0 : 1); t < P::NTT; t++) add4(A[e], xq1[e * XS + lane + KS * (OT + P::S1 * t)]);
+#pragma unroll
+          for (int v = (P::NU + P::NTT > 0 ? 0 : 1); v < P::NVV; v++) add4(A[e], xq0[e * XS + lane + KS * (OV + v)]);
+        }
+        if (tex_now) {
+#pragma unroll
+          for (int u = 1; u < P::NU; u++) tA += xt_of(xq2)[lane + KS * P::SP2 * u];
+#pragma unroll
+          for (int t = (P::NU > 0 ? 0 : 1); t < P::NTT; t++) tA += xt_of(xq1)[lane + KS * (OT + P::S1 * t)];
+#pragma unroll
+          for (int v = (P::NU + P::NTT > 0 ? 0 : 1); v < P::NVV; v++) tA += xt_of(xq0)[lane + KS * (OV + v)];
+          // the verdict crosses the winner search as a wavefront-uniform mask, not in a vector register
+          tex_ok = __ballot((int)tA >= a.tex);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < XCH / 2; e++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) S[2 * (q0 + 2 * e) + i] = A[e][i];
       __builtin_amdgcn_wave_barrier();
     }
-    // the texture partners are read now (the exchange area is about to receive the next entering row); the verdict crosses
-    // the winner search as a wavefront-uniform mask, not in a vector register
-    unsigned long long tex_ok;
-    {
-      int tsum = (int)Vt;
-#pragma unroll
-      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + KS * k];
-      tex_ok = __ballot(tsum >= a.tex);
-    }
+    // level 0 of the exchange is about to receive the next entering row
     reads_done();
     stage(min(y + 1 + W2, a.H - 1), b0);
     __builtin_amdgcn_s_setprio(0);
@@ -944,33 +1046,74 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, uint4* __r
       acc = ac[0];
     }
 
-    // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) via a byte-permute selection tree -------------
+    // ---- neighbours S[mind-1], S[mind+1] (mirrored at the ends) ----------------------------------------------------------
     const int in_ = mind > 0 ? mind - 1 : 1;
     const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
     const int ln = min(max(in_ - d0, 0), NDW - 1), lp = min(max(ip_ - d0, 0), NDW - 1);  // local (clamped) indices
-    u32 X[NQ];
-    const u32 lnp = (u32)ln | ((u32)lp << 16);
-    {
-      // bytes (2a, 2a+1) with a = index & 3:  0x0100 + a * 0x0202 per half
-      const u32 sel = __umul24(lnp & 0x00030003u, 0x0202u) + 0x01000100u;
+    u32 X0;
+    if constexpr (D::NBR) {
+      // through LDS: S goes out register by register with ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address
+      // VGPR, 2 LDS cycles per wavefront-instruction where a ds_write_b128 costs 13 -- tools/ubench/gen_probe3.py), [register]
+      // [lane] dwords, NPH phases of NR / NPH registers through one area; a lane reads its two entries (local index i: register
+      // i >> 1, half i & 1) in every phase and keeps the one of the right phase. Conflict-free: a lane only touches its column.
+      constexpr int PHR = NR / D::NPH;                     // registers per phase
+      const u32 m0v = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)dumpc);   // (LDS byte address = low half of the flat address)
+      const u32 l4 = lane_u * 4u;
+      const u32 an = ((((u32)ln >> 1) % (u32)PHR) << 8) + (((u32)ln & 1u) << 1) + l4;
+      const u32 ap = ((((u32)lp >> 1) % (u32)PHR) << 8) + (((u32)lp & 1u) << 1) + l4;
+      u32 vn = 0, vp = 0;
 #pragma unroll
-      for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
-    }
-    {
-      int lvl = 2;
+      for (int ph = 0; ph < D::NPH; ph++) {
+        if (ph > 0) reads_done();
 #pragma unroll
-      for (int n = NQ; n > 1; n >>= 1) {
-        const u32 sel = __umul24((lnp >> lvl) & 0x00010001u, 0x0404u) + 0x03020100u;
-#pragma unroll
-        for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
-        lvl++;
+        for (int k = 0; k < PHR; k += 8) {
+          const int j = ph * PHR + k;
+          asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+                       "ds_write_addtid_b32 %0 offset:%9\n\tds_write_addtid_b32 %1 offset:%9+256\n\t"
+                       "ds_write_addtid_b32 %2 offset:%9+512\n\tds_write_addtid_b32 %3 offset:%9+768\n\t"
+                       "ds_write_addtid_b32 %4 offset:%9+1024\n\tds_write_addtid_b32 %5 offset:%9+1280\n\t"
+                       "ds_write_addtid_b32 %6 offset:%9+1536\n\tds_write_addtid_b32 %7 offset:%9+1792"
+                       :: "v"(S[j]), "v"(S[j + 1]), "v"(S[j + 2]), "v"(S[j + 3]), "v"(S[j + 4]), "v"(S[j + 5]), "v"(S[j + 6]), "v"(S[j + 7]),
+                          "s"(m0v), "n"(k * 256) : "m0", "memory");
+        }
+        published();
+        const u32 rn = *reinterpret_cast<const unsigned short*>(dumpc + an);
+        const u32 rp = *reinterpret_cast<const unsigned short*>(dumpc + ap);
+        if constexpr (D::NPH == 1) {
+          vn = rn; vp = rp;
+        } else {
+          vn = (ln >> 1) / PHR == ph ? rn : vn;
+          vp = (lp >> 1) / PHR == ph ? rp : vp;
+        }
       }
+      X0 = vn | (vp << 16);
+    } else {
+      // via a byte-permute selection tree
+      u32 X[NQ];
+      const u32 lnp = (u32)ln | ((u32)lp << 16);
+      {
+        // bytes (2a, 2a+1) with a = index & 3:  0x0100 + a * 0x0202 per half
+        const u32 sel = __umul24(lnp & 0x00030003u, 0x0202u) + 0x01000100u;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) X[q] = __builtin_amdgcn_perm(S[2 * q + 1], S[2 * q], sel);
+      }
+      {
+        int lvl = 2;
+#pragma unroll
+        for (int n = NQ; n > 1; n >>= 1) {
+          const u32 sel = __umul24((lnp >> lvl) & 0x00010001u, 0x0404u) + 0x03020100u;
+#pragma unroll
+          for (int m = 0; m < n / 2; m++) X[m] = __builtin_amdgcn_perm(X[2 * m + 1], X[2 * m], sel);
+          lvl++;
+        }
+      }
+      X0 = X[0];
     }
-    int nn = (int)(X[0] & 0xffffu), pp = (int)(X[0] >> 16);
+    int nn = (int)(X0 & 0xffffu), pp = (int)(X0 >> 16);
     u32 acc_lo = acc & 0xffffu, acc_hi = acc >> 16;
     bool mine = true;  // does this wavefront finalise this row?
     if constexpr (NWAVES > 1) {
-      xacc[mpar + wv * 64 + lane] = make_uint2(acc, X[0]);
+      xacc[mpar + wv * 64 + lane] = make_uint2(acc, X0);
       __syncthreads();
       mine = (y % NWAVES) == wv;
       if (mine) {
@@ -1061,31 +1204,31 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     strip = inner;
   }
   // LDS of the workgroup: per wavefront one area of WSLOT slots (staged row / exchange) + the merge area of the workgroup;
-  // single-wavefront workgroups (LDS-direct staging): two areas of WSLOT slots, 64 left-pattern dwords behind each
+  // LDS-direct strips: per wavefront the areas of DmaLds (two staged rows, further exchange levels, S dump), then the merge area
   const int wvk = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-  constexpr int PADS = fast_dma(NDW, NWAVES) ? 16 : 0;   // the 64 left-pattern dwords behind a staged-row area (LDS-direct staging)
+  unsigned char* const ldsb = reinterpret_cast<unsigned char*>(fast_lds);
+  auto dma_strip = [&](auto cs_tag, const int cb) {
+    constexpr int CSV = decltype(cs_tag)::value;
+    using D = DmaLds<NDW, NWAVES, NTERM, PW, CSV>;
+    unsigned char* const wb = ldsb + wvk * D::WAVE_B;
+    unsigned char* const xl = wb + 2 * D::AREA_B;
+    sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, CSV>(a, wb, wb + D::AREA_B, xl, xl + (D::P::NLEV > 2 ? D::XLEV_B : 0),
+                                                            xl + (D::P::NLEV - 1) * D::XLEV_B, reinterpret_cast<u32*>(ldsb + NWAVES * D::WAVE_B), cb, segi, pair);
+  };
   if constexpr (DUAL) {
     constexpr int NV3 = 64 - (NTERM - 1), NV1 = 64 - PW * (NTERM - 1);
-    constexpr int WS3 = FastLds<NDW, NTERM, PW, 3>::WSLOT, WS1 = FastLds<NDW, NTERM, PW, 1>::WSLOT;
     if (strip < a.strips3) {
       const int t = strip / 3;
-      if constexpr (fast_dma(NDW, NWAVES))
-        sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, 3>(a, fast_lds + wvk * 2 * (WS3 + PADS), fast_lds + wvk * 2 * (WS3 + PADS) + WS3 + PADS,
-                                                              reinterpret_cast<u32*>(fast_lds + NWAVES * 2 * (WS3 + PADS)), t * (3 * NV3) + (strip - 3 * t), segi, pair);
+      if constexpr (fast_dma(NDW, NWAVES)) dma_strip(std::integral_constant<int, 3>{}, t * (3 * NV3) + (strip - 3 * t));
       else sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 3>(a, t * (3 * NV3) + (strip - 3 * t), segi, pair);
     } else {
       const int cb1 = (a.strips3 / 3) * (3 * NV3) + (strip - a.strips3) * NV1;
-      if constexpr (fast_dma(NDW, NWAVES))
-        sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, fast_lds + wvk * 2 * (WS1 + PADS), fast_lds + wvk * 2 * (WS1 + PADS) + WS1 + PADS,
-                                                              reinterpret_cast<u32*>(fast_lds + NWAVES * 2 * (WS1 + PADS)), cb1, segi, pair);
+      if constexpr (fast_dma(NDW, NWAVES)) dma_strip(std::integral_constant<int, 1>{}, cb1);
       else sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, cb1, segi, pair);
     }
   } else {
     constexpr int NV1 = 64 - PW * (NTERM - 1);
-    constexpr int WS1 = FastLds<NDW, NTERM, PW, 1>::WSLOT;
-    if constexpr (fast_dma(NDW, NWAVES))
-      sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, fast_lds + wvk * 2 * (WS1 + PADS), fast_lds + wvk * 2 * (WS1 + PADS) + WS1 + PADS,
-                                                            reinterpret_cast<u32*>(fast_lds + NWAVES * 2 * (WS1 + PADS)), strip * NV1, segi, pair);
+    if constexpr (fast_dma(NDW, NWAVES)) dma_strip(std::integral_constant<int, 1>{}, strip * NV1);
     else sad_fast_strip<NDW, NWAVES, NTERM, PW, EXACT_ND, 1>(a, strip * NV1, segi, pair);
   }
 }
@@ -1201,8 +1344,10 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   // per wavefront the staged-row / exchange area; then the workgroup's merge area, or -- single-wavefront workgroups with
   // LDS-direct staging -- the second staged-row area
   size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
-  if (fast_dma(NDW, NWAVES))   // per wavefront two areas of WSLOT slots + 64 pattern dwords each, then the merge area
-    lds = (size_t)NWAVES * 2 * (WSLOTM + 16) * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  if (fast_dma(NDW, NWAVES)) {  // per wavefront the areas of DmaLds, then the merge area
+    constexpr int WB1 = DmaLds<NDW, NWAVES, NTERM, PW, 1>::WAVE_B, WB3 = DmaLds<NDW, NWAVES, NTERM, PW, DUAL ? 3 : 1>::WAVE_B;
+    lds = (size_t)NWAVES * (WB1 > WB3 ? WB1 : WB3) + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
+  }
   a.bord = a.bnw = 0;
   if (border) {
     // border wavefronts per segment: 2 sides x ceil(n / JW) groups of JW consecutive pairs, NWAVES of them per workgroup
