@@ -29,19 +29,25 @@
  * at cap 31 is 27 342): OpenCV keeps its block-matching cost plane as `short`, so beyond that bound its left-right check
  * would see a wrapped cost where this engine (and its oracle) keep the true one.
  *
- * Environment. The library reads these variables (nothing else); an integrator never needs to set any of them:
+ * Environment. The library reads these seven variables (nothing else); an integrator never needs to set any of them:
  *   variable            default  read      who sets it, and what for
  *   SBM_FAST_INPLACE    1        once      0 = run the two-accumulator build of the SAD kernel (the fallback that is taken
  *                                          automatically when the device self-test of the in-place v_mqsad accumulate
  *                                          fails); set by the GPU tests to check that fallback
- *   SBM_FAST_MODE       1        once      0 = 64 disparities per wavefront (round-2 layout), 2 = two 128-disparity wavefronts
- *                                          beyond 192 disparities; GPU tests / A-B measurements
+ *   SBM_FAST_MODE       2        once      layout of the interior SAD kernel beyond 64 disparities: 2 = one 128-disparity
+ *                                          wavefront up to 128, two of them beyond (three 64-disparity ones at exactly 192);
+ *                                          1 = one 128-disparity wavefront up to 128, 64-disparity cooperating wavefronts
+ *                                          beyond; 0 = 64 disparities per wavefront everywhere (round-2 layout); GPU tests /
+ *                                          A-B measurements
  *   SBM_FAST_PFSHIFT    2        once      0 = unscaled prefiltered planes (plain winner search), 1 = at most one tag bit;
  *                                          GPU tests
  *   SBM_FAST_CS3        1        per call  0 = plain column strips only (no column-stride-3 strips); GPU tests
  *   SBM_SPECKLE_LISTS   1        per call  0 = row-walking count / apply kernels of the speckle filter; GPU tests
  *   SBM_SPECKLE_BAND    auto     per call  0 / 2 / 4 / 8 = band height of the speckle filter's band walk (0: round-1 kernels);
  *                                          GPU tests
+ *   SBM_HOST_ZEROCOPY   1        once      0 = small host-buffer calls (sbm_compute / sbm_compute_batch up to 8 MB of maps) return
+ *                                          their maps through a D2H copy + stream synchronisation instead of the copy kernel that
+ *                                          writes pinned host memory and raises a flag the host polls; GPU tests / A-B measurements
  * Tuning knobs of the measurement scripts (SBM_FAST_TARGET, SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
  * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*) exist only in development builds (-DSBM_DEV,
  * tools/exp/r04_devlib.sh); this library ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this
@@ -161,6 +167,23 @@ int sbm_wait_oldest(sbm_handle* h);
 /* Block until everything queued on the handle's stream has finished and every outstanding submission of the asynchronous
  * feed has delivered its maps. */
 int sbm_synchronize(sbm_handle* h);
+
+/* sbm_destroy() and the asynchronous feed: copies that are already queued finish first (so the `disp` buffer of every
+ * submission that was followed by another submission or by a wait must still exist when the handle is destroyed); the maps of
+ * the NEWEST submission, whose trip home is only queued by the next submission or by a wait, are dropped -- destroy never
+ * starts a write into caller memory. Callers that want those maps call sbm_synchronize() first. */
+
+/* One dense host batch spread over several engines -- normally one handle per GPU of the node, created with
+ * sbm_create(&h[k], &params, k) ("pair batches shard embarrassingly across the GPUs"; the reference's
+ * caller is a single C++ thread, src/slam/src/core/main.cpp:149-216). left / right: n*height*width bytes, disp:
+ * n*height*width int16, HOST memory that should be pinned (pageable memory works, but the runtime then stages every copy
+ * synchronously and the devices run one after the other). Handle k computes the contiguous block of pairs
+ * [n*k/K, n*(k+1)/K) through its asynchronous feed (two submissions per block); all blocks are queued before any is waited
+ * for. Blocking: on return every map is in `disp`. The handles must be distinct (SBM_ERR_BATCH otherwise), may sit on the same
+ * or on different devices and keep their own parameter blocks; results equal sbm_compute_batch() of each block on its handle.
+ * Every handle is drained even when one of them fails; the first failure is returned. */
+int sbm_compute_batch_multi(sbm_handle* const* handles, int n_handles, int n, const uint8_t* left, const uint8_t* right,
+                            int width, int height, int16_t* disp);
 
 /* Intermediate planes of the LAST sbm_compute_device call, for stage-by-stage parity tests.
  * which: 0 = prefiltered left (u8), 1 = prefiltered right (u8), 2 = WTA cost plane (int32, valid only

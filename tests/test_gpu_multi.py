@@ -1,0 +1,122 @@
+"""The C++ caller's multi-engine path (sbm_compute_batch_multi) and the thread-safety promise of include/sbm.h, on whatever
+the box has: one handle per visible device, and -- so that a one-GPU box still exercises the block partition and the shared
+state (parked-handle pool, device self-test, kernel-name buffer) -- two engines / two host threads on device 0."""
+import pathlib
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def _build(tmp_path, pkg):
+    exe = tmp_path / "multi_main"
+    lib = pkg.library_path()
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I", str(ROOT / "include"), "-I", "/opt/rocm/include",
+                        str(ROOT / "tests" / "cpp" / "multi_main.cpp"), "-o", str(exe), str(lib), "-L/opt/rocm/lib", "-lamdhip64",
+                        f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    return exe, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_dev", [1, 2])
+def test_cpp_multi_engine_and_two_threads(tmp_path, pkg, oracle, golden, per_dev):
+    """tests/cpp/multi_main.cpp: whole batch on one handle == sbm_compute_batch_multi over one (two) handle(s) per visible
+    device == two host threads with their own handles calling sbm_compute pair by pair; and all of it == the oracle."""
+    exe, r = _build(tmp_path, pkg)
+    assert r.returncode == 0, r.stderr
+    L0, R0 = golden["rect_l"], golden["rect_r"]
+    n = 7                                          # odd: uneven blocks and halves
+    frames_l = np.stack([np.roll(L0, 5 * i, axis=1) if i % 2 == 0 else np.roll(L0[::-1], 3 * i, axis=1) for i in range(n)])
+    frames_r = np.stack([np.roll(R0, 5 * i, axis=1) if i % 2 == 0 else np.roll(R0[::-1], 3 * i, axis=1) for i in range(n)])
+    (tmp_path / "l.raw").write_bytes(frames_l.tobytes())
+    (tmp_path / "r.raw").write_bytes(frames_r.tobytes())
+    run = subprocess.run([str(exe), "640", "480", str(n), str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(tmp_path), str(per_dev)],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert "OK" in run.stdout
+    p = oracle.make_params(64, 21, 31, 0, 10, 10, 50, 32, 1)      # the parameters of main.cpp:204-212
+    for name in ("single", "multi", "threads"):
+        got = np.frombuffer((tmp_path / f"{name}.raw").read_bytes(), np.int16).reshape(n, 480, 640)
+        for i in (0, 3, n - 1):
+            ref = oracle.compute(p, frames_l[i], frames_r[i])
+            assert np.array_equal(got[i], ref), (name, i, int((got[i] != ref).sum()))
+
+
+@pytest.mark.gpu
+def test_compute_multi_blocks_python(pkg, oracle, torch_cuda):
+    """compute_multi over engines with DIFFERENT parameter blocks: every block equals what its own engine computes alone
+    (handles keep their parameters; blocks are contiguous, [n k / K, n (k + 1) / K))."""
+    from u96_slam_amd import synth
+
+    torch = torch_cuda
+    n, W, H = 5, 320, 96
+    L, R = synth.make_batch(11, n, W, H, 64)
+    ndev = torch.cuda.device_count()
+    engines = []
+    for k in range(max(3, ndev)):
+        bm = pkg.StereoBM.create(64 if k % 2 == 0 else 32, 15 if k % 3 else 9, device=k % ndev)
+        bm.setUniquenessRatio(10); bm.setDisp12MaxDiff(1); bm.setSpeckleWindowSize(30); bm.setSpeckleRange(16)
+        engines.append(bm)
+    Lp, Rp = torch.from_numpy(L).pin_memory().numpy(), torch.from_numpy(R).pin_memory().numpy()
+    out = torch.empty((n, H, W), dtype=torch.int16).pin_memory().numpy()
+    pkg.compute_multi(engines, Lp, Rp, out)
+    K = len(engines)
+    for k, bm in enumerate(engines):
+        b0, b1 = n * k // K, n * (k + 1) // K
+        if b1 > b0:
+            p = oracle.make_params(bm.getNumDisparities(), bm.getBlockSize(), 31, 0, 10, 10, 30, 16, 1)
+            for i in range(b0, b1):
+                assert np.array_equal(out[i], oracle.compute(p, L[i], R[i])), (k, i)
+    with pytest.raises(pkg.StereoBMError):
+        pkg.compute_multi([engines[0], engines[0]], Lp, Rp, out)
+
+
+@pytest.mark.gpu
+def test_every_visible_device_gets_a_handle(pkg, oracle, torch_cuda):
+    """A handle on every visible device computes the same map (device != 0 only exists on multi-GPU boxes; the loop still
+    runs on one GPU)."""
+    from u96_slam_amd import synth
+
+    torch = torch_cuda
+    L, R = synth.make_batch(5, 1, 400, 80, 64)
+    p = oracle.make_params(64, 15, 31, 0, 10, 15, 0, 0, -1)
+    ref = oracle.compute(p, L[0], R[0])
+    for d in range(torch.cuda.device_count()):
+        bm = pkg.StereoBM.create(64, 15, device=d)
+        assert np.array_equal(bm.compute(L[0], R[0]), ref), d
+
+
+@pytest.mark.gpu
+def test_two_python_threads_two_engines(pkg, oracle, torch_cuda):
+    """Two host threads, each creating / using / dropping its own engines on device 0 (ctypes releases the GIL inside the
+    C calls, so the library's shared state -- handle pool, once-per-device self-test -- really is entered concurrently)."""
+    from u96_slam_amd import synth
+
+    L, R = synth.make_batch(9, 4, 320, 96, 64)
+    want = {}
+    for w in (9, 15):
+        p = oracle.make_params(64, w, 31, 0, 10, 10, 30, 16, 1)
+        want[w] = [oracle.compute(p, L[i], R[i]) for i in range(4)]
+    errs = []
+
+    def worker(w):
+        try:
+            for rep in range(6):
+                bm = pkg.StereoBM.create(64, w)
+                bm.setUniquenessRatio(10); bm.setDisp12MaxDiff(1); bm.setSpeckleWindowSize(30); bm.setSpeckleRange(16)
+                for i in range(4):
+                    if not np.array_equal(bm.compute(L[i], R[i]), want[w][i]):
+                        errs.append((w, rep, i))
+                del bm
+        except Exception as e:      # noqa: BLE001
+            errs.append((w, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in (9, 15)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:5]

@@ -14,8 +14,9 @@ def _cv2():
 
         return cv2
     except Exception as e:  # noqa: BLE001
-        pytest.skip(f"OpenCV unavailable on this box (import cv2: {type(e).__name__}): cv::StereoBM parity stays unpinned; "
-                    "the engine is checked against the in-repo restatement instead")
+        pytest.skip(f"OpenCV unavailable on this box (import cv2: {type(e).__name__}): cv::StereoBM parity stays unpinned; the engine is "
+                    "checked against the in-repo restatement instead. To settle it off-box: python tools/verify_with_opencv.py "
+                    "tests/golden/pin_kit.npz (numpy + cv2 only) -- the kit holds this engine's stage-by-stage outputs for every risk case")
 
 
 def _cv_bm(cv2, nd, w):
@@ -53,3 +54,70 @@ def test_synthetic_frames_against_opencv(pkg, shape):
     m = _cv_bm(cv2, nd, w)
     for i in range(n):
         assert np.array_equal(got[i], m.compute(L[i], R[i])), i
+
+
+# ---- the pin kit (tools/pin_kit.py): one case per risk item of SURVEY.md A.7 + getValidDisparityROI's "- minDisparity" --------
+def _kit():
+    import pathlib
+
+    path = pathlib.Path(__file__).resolve().parents[1] / "tests" / "golden" / "pin_kit.npz"
+    if not path.exists():
+        pytest.skip("tests/golden/pin_kit.npz not generated yet (python tools/pin_kit.py on a GPU box)")
+    return np.load(path)
+
+
+def _engine(pkg, q):
+    bm = pkg.StereoBM.create(q["num_disparities"], q["block_size"])
+    bm.setPreFilterType(q["prefilter_type"]); bm.setPreFilterSize(q["prefilter_size"]); bm.setPreFilterCap(q["prefilter_cap"])
+    bm.setMinDisparity(q["min_disparity"]); bm.setTextureThreshold(q["texture_threshold"]); bm.setUniquenessRatio(q["uniqueness_ratio"])
+    bm.setSpeckleWindowSize(q["speckle_window_size"]); bm.setSpeckleRange(q["speckle_range"]); bm.setDisp12MaxDiff(q["disp12_max_diff"])
+    bm.setROI1((q["roi1_x"], q["roi1_y"], q["roi1_w"], q["roi1_h"])); bm.setROI2((q["roi2_x"], q["roi2_y"], q["roi2_w"], q["roi2_h"]))
+    return bm
+
+
+def _stage(p, st):
+    q = dict(p)
+    if st == "s0_wta":
+        q.update(uniqueness_ratio=0, texture_threshold=0, disp12_max_diff=-1, speckle_window_size=0, speckle_range=0)
+    elif st == "s1_uniq":
+        q.update(disp12_max_diff=-1, speckle_window_size=0, speckle_range=0)
+    elif st == "s2_lr":
+        q.update(speckle_window_size=0, speckle_range=0)
+    return q
+
+
+def test_engine_reproduces_the_pin_kit(pkg):
+    """No OpenCV needed: the committed kit is what THIS engine computes today (a kernel change that moves a single pixel of any
+    risk case fails here, before anybody spends an OpenCV box on a stale kit)."""
+    kit = _kit()
+    fields = [str(f) for f in kit["fields"]]
+    for name in kit["names"]:
+        name = str(name)
+        p = dict(zip(fields, kit[f"{name}/params"].tolist()))
+        for st in kit["stages"]:
+            got = _engine(pkg, _stage(p, str(st))).compute(kit[f"{name}/left"], kit[f"{name}/right"])
+            assert np.array_equal(got, kit[f"{name}/{st}"]), (name, str(st), int((got != kit[f"{name}/{st}"]).sum()))
+
+
+def test_pin_kit_against_opencv():
+    """The one-command pin, run in-tree where a box has cv2: every risk case, first differing stage reported."""
+    cv2 = _cv2()
+    import importlib.util
+    import pathlib
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("verify_with_opencv", root / "tools" / "verify_with_opencv.py")
+    ver = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ver)
+    kit = _kit()
+    fields = [str(f) for f in kit["fields"]]
+    bad = []
+    for name in kit["names"]:
+        name = str(name)
+        p = dict(zip(fields, kit[f"{name}/params"].tolist()))
+        for st in kit["stages"]:
+            got = ver.make_bm(cv2, ver.stage_params(p, str(st))).compute(kit[f"{name}/left"], kit[f"{name}/right"])
+            if not np.array_equal(got, kit[f"{name}/{st}"]):
+                bad.append((name, str(st), int((got != kit[f"{name}/{st}"]).sum())))
+                break
+    assert not bad, bad

@@ -1,0 +1,71 @@
+"""The pin kit (tools/pin_kit.py -> tests/golden/pin_kit.npz): inputs, parameter blocks and the ENGINE's stage-by-stage outputs
+for one case per bit-exactness risk of SURVEY.md A.7. CPU-side: the kit's hashes are what the manifest says, the oracle
+reproduces every stored output (kit == engine == oracle), and the stand-alone verifier's helpers agree with the generator's.
+Settling kit == cv::StereoBM needs OpenCV: `python tools/verify_with_opencv.py tests/golden/pin_kit.npz` on any box that has it."""
+import hashlib
+import importlib.util
+import pathlib
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+KIT = ROOT / "tests" / "golden" / "pin_kit.npz"
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def kit():
+    if not KIT.exists():
+        pytest.skip("tests/golden/pin_kit.npz not generated yet (python tools/pin_kit.py on a GPU box)")
+    return np.load(KIT)
+
+
+def test_manifest_hashes(kit):
+    lines = KIT.with_suffix(".sha256").read_text().splitlines()
+    want = {l.split()[1]: l.split()[0] for l in lines}
+    assert sorted(want) == sorted(str(n) for n in kit["names"])
+    for name in want:
+        h = hashlib.sha256()
+        for key in ("left", "right", "params", *[str(s) for s in kit["stages"]]):
+            h.update(np.ascontiguousarray(kit[f"{name}/{key}"]).tobytes())
+        assert h.hexdigest() == want[name], name
+
+
+def test_oracle_reproduces_every_stage(kit, oracle):
+    gen = _load(ROOT / "tools" / "pin_kit.py", "pin_kit_gen")
+    ver = _load(ROOT / "tools" / "verify_with_opencv.py", "pin_kit_ver")
+    fields = [str(f) for f in kit["fields"]]
+    assert tuple(fields) == gen.FIELDS
+    n = 0
+    for name in kit["names"]:
+        name = str(name)
+        p = dict(zip(fields, kit[f"{name}/params"].tolist()))
+        L, R = kit[f"{name}/left"], kit[f"{name}/right"]
+        for st in kit["stages"]:
+            q = ver.stage_params(p, str(st))          # the verifier's own staging, not the generator's
+            po = oracle.make_params(q["num_disparities"], q["block_size"], q["prefilter_cap"], q["min_disparity"], q["texture_threshold"],
+                                    q["uniqueness_ratio"], q["speckle_window_size"], q["speckle_range"], q["disp12_max_diff"],
+                                    q["prefilter_type"], q["prefilter_size"], (q["roi1_x"], q["roi1_y"], q["roi1_w"], q["roi1_h"]),
+                                    (q["roi2_x"], q["roi2_y"], q["roi2_w"], q["roi2_h"]))
+            assert np.array_equal(oracle.compute(po, L, R), kit[f"{name}/{st}"]), (name, str(st))
+            n += 1
+    assert n >= 4 * 20
+
+
+def test_kit_covers_the_risk_list(kit):
+    names = {str(n) for n in kit["names"]}
+    for must in ("ref_pair_w21_callsite", "mind_neg8_rois", "mind_pos4_rois", "cost_w17_cap63", "cost_w23_cap31", "odd_height",
+                 "speckle_range1", "speckle_range16", "lr_ties_d12_1", "prefilter_norm_9"):
+        assert must in names
+    # the stages really separate the filters somewhere
+    assert not np.array_equal(kit["speckle_range1/s3_full"], kit["speckle_range16/s3_full"])
+    assert not np.array_equal(kit["ref_pair_w21_callsite/s1_uniq"], kit["ref_pair_w21_callsite/s0_wta"])
+    assert not np.array_equal(kit["ref_pair_w21_callsite/s2_lr"], kit["ref_pair_w21_callsite/s1_uniq"])
+    assert not np.array_equal(kit["ref_pair_w21_callsite/s3_full"], kit["ref_pair_w21_callsite/s2_lr"])

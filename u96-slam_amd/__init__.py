@@ -12,8 +12,8 @@ GPU raises. The CPU oracle lives in /oracle and is only used by the tests and by
 """
 from .stereobm import (StereoBM, StereoBMError, SbmParams, StereoModel, library_path, load_library, PREFILTER_XSOBEL,  # noqa: F401
                        PREFILTER_NORMALIZED_RESPONSE, RectCam, make_rect_cam, PREFILTER_FLAVOUR_CV, PREFILTER_FLAVOUR_RTL, trim,
-                       FpgaParams, fpga_params, fpga_params_from_regs, fpga_sad_size_reg, fpga_validate)
+                       FpgaParams, fpga_params, fpga_params_from_regs, fpga_sad_size_reg, fpga_validate, compute_multi)
 
 __all__ = ["StereoBM", "StereoBMError", "SbmParams", "StereoModel", "library_path", "load_library", "PREFILTER_XSOBEL",
            "PREFILTER_NORMALIZED_RESPONSE", "RectCam", "make_rect_cam", "PREFILTER_FLAVOUR_CV", "PREFILTER_FLAVOUR_RTL", "trim",
-           "FpgaParams", "fpga_params", "fpga_params_from_regs", "fpga_sad_size_reg", "fpga_validate"]
+           "FpgaParams", "fpga_params", "fpga_params_from_regs", "fpga_sad_size_reg", "fpga_validate", "compute_multi"]

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <new>
 
@@ -44,6 +45,13 @@ struct sbm_handle {
   int16_t* st_d;
   uint8_t* pin;        // pinned host staging for strided caller images (rows packed / unpacked on the CPU)
   size_t pin_bytes;
+  // small host-buffer calls (the reference's one pair per call): the maps leave through a copy kernel that writes pinned,
+  // device-mapped host memory and raises a flag there; the host polls the flag instead of synchronising the stream
+  int16_t* zc_out;     // pinned + mapped host staging of the maps
+  size_t zc_bytes;
+  unsigned* zc_flag;   // pinned + mapped: sequence number of the last call whose maps are complete in zc_out
+  unsigned* zc_cnt;    // device: workgroups of the copy kernel that have finished (the last one raises the flag and clears it)
+  unsigned zc_seq;
   // copy streams + per-chunk events of the pipelined host batch path (created on first use)
   hipStream_t stream_in, stream_out;
   // asynchronous dense feed (sbm_submit_dense / sbm_wait_oldest): two device staging sets, up to three submissions in
@@ -86,6 +94,30 @@ struct DeviceScope {
     if (have && prev != dev) hipSetDevice(prev);
   }
 };
+
+#ifdef SBM_DEV   // development builds: wall-clock stamps of the host-buffer entry point's phases (tools/exp/r05_host_attrib.py)
+static double g_hp_acc[8];
+static unsigned long long g_hp_calls;
+struct HostProf {
+  std::chrono::steady_clock::time_point t;
+  HostProf() : t(std::chrono::steady_clock::now()) {}
+  void stamp(int i) {
+    const auto n = std::chrono::steady_clock::now();
+    g_hp_acc[i] += std::chrono::duration<double, std::micro>(n - t).count();
+    t = n;
+  }
+};
+#define HP_BEGIN() HostProf hp_; g_hp_calls++
+#define HP(i) hp_.stamp(i)
+extern "C" int sbm_dev_host_prof(double* out8, unsigned long long* calls) {
+  for (int i = 0; i < 8; i++) { out8[i] = g_hp_acc[i]; g_hp_acc[i] = 0; }
+  *calls = g_hp_calls; g_hp_calls = 0;
+  return 0;
+}
+#else
+#define HP_BEGIN() do { } while (0)
+#define HP(i) do { } while (0)
+#endif
 
 #define HIPCHK(h, call)                         \
   do {                                          \
@@ -180,6 +212,10 @@ static void free_staging(sbm_handle* h) {
   hipFree(h->st_l); hipFree(h->st_r); hipFree(h->st_d);
   if (h->pin) hipHostFree(h->pin);
   h->pin = nullptr; h->pin_bytes = 0;
+  if (h->zc_out) hipHostFree(h->zc_out);
+  if (h->zc_flag) hipHostFree(h->zc_flag);
+  hipFree(h->zc_cnt);
+  h->zc_out = nullptr; h->zc_flag = nullptr; h->zc_cnt = nullptr; h->zc_bytes = 0;
   h->st_l = h->st_r = nullptr; h->st_d = nullptr; h->st_n = h->st_W = h->st_H = 0;
 }
 
@@ -266,12 +302,11 @@ void sbm_destroy(sbm_handle* h) {
   if (!h) return;
   DeviceScope dscope(h->device);
   dscope.enter();
-  // submissions of the asynchronous feed nobody waited for: deliver their maps (the newest one's trip home is only queued by
-  // a wait), then forget the queue whatever happened
-  while (h->fq_waited != h->fq_submitted)
-    if (sbm_wait_oldest(h) != SBM_OK) break;
-  h->fq_waited = h->fq_submitted;
+  // submissions of the asynchronous feed nobody waited for: the copies that are already queued finish (their destination
+  // must still exist, as for any submission that has not been waited for); the newest submission's maps, whose trip home is
+  // only queued by a wait or by the next submission, are DROPPED -- destroy never starts a write into caller memory
   h->fq_pending_dst = nullptr;
+  h->fq_waited = h->fq_submitted;
   sync_all_streams(h);
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -1027,6 +1062,107 @@ int sbm_submit_dense(sbm_handle* h, int n, const uint8_t* left, const uint8_t* r
   return SBM_OK;
 }
 
+// Maps of a small host-buffer call on their way out (the reference's pattern: one 640x480 pair per call, main.cpp:201-216).
+// A D2H copy into pageable memory costs the call ~70 us after the last kernel (the runtime stages it: DMA + CPU copy) and the
+// stream synchronisation behind it another ~15 (profiles/r05_host_attrib.txt). Instead the last kernel of the call copies the
+// maps into pinned, device-mapped host memory and raises a sequence flag there (last workgroup done, system-scope release);
+// the host spins on the flag and copies the rows to the caller itself.
+__global__ void __launch_bounds__(256) maps_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, const int16_t* __restrict__ src_tail,
+                                                       int16_t* __restrict__ dst_tail, int ntail, unsigned* cnt, unsigned* flag, unsigned seq) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
+    __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (done == gridDim.x) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+static int ensure_zc(sbm_handle* h, size_t bytes) {
+  if (h->zc_out && h->zc_bytes >= bytes) return SBM_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->zc_out) hipHostFree(h->zc_out);
+  h->zc_out = nullptr; h->zc_bytes = 0;
+  HIPCHK(h, hipHostMalloc((void**)&h->zc_out, bytes + 64, hipHostMallocMapped | hipHostMallocCoherent));
+  h->zc_bytes = bytes;
+  if (!h->zc_flag) {
+    HIPCHK(h, hipHostMalloc((void**)&h->zc_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *h->zc_flag = 0u;
+    h->zc_seq = 0u;
+  }
+  if (!h->zc_cnt) {
+    HIPCHK(h, hipMalloc((void**)&h->zc_cnt, 64));
+    HIPCHK(h, hipMemsetAsync(h->zc_cnt, 0, 64, h->stream));
+  }
+  return SBM_OK;
+}
+
+// queue the copy kernel behind the call's kernels and wait for its flag; on return the maps are in h->zc_out
+static int maps_out_and_wait(sbm_handle* h, const int16_t* d_src, size_t count) {
+  const size_t bytes = count * sizeof(int16_t);
+  int st = ensure_zc(h, bytes);
+  if (st != SBM_OK) return st;
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)((bytes - n16 * 16) / 2);
+  const unsigned seq = ++h->zc_seq == 0u ? ++h->zc_seq : h->zc_seq;   // (0 is "nothing yet")
+  const unsigned blocks = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (n16 + 511) / 512));
+  hipLaunchKernelGGL(maps_out_kernel, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(h->zc_out), n16,
+                     d_src + n16 * 8, h->zc_out + n16 * 8, ntail, h->zc_cnt, h->zc_flag, seq);
+  HIPCHK(h, hipGetLastError());
+  // spin on the flag; a stream that has failed never raises it, so fall back to the runtime's own wait after a while
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(h->zc_flag, __ATOMIC_ACQUIRE) != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      break;
+    }
+  }
+  return SBM_OK;
+}
+
+// One dense host batch over several engines -- the C++ caller's form of "pair batches shard across the GPUs of a node"
+// (one process, one stream set per device): handle k takes the contiguous block of pairs
+// [n k / K, n (k + 1) / K), cut into at most two submissions of its asynchronous feed so that the second half's inputs cross
+// PCIe while the first half computes; every device's submissions are queued before anything is waited for, so the devices run
+// side by side from ONE host thread. Pairs are independent: no data-path collective, the blocks' maps land in `disp` in place.
+int sbm_compute_batch_multi(sbm_handle* const* handles, int n_handles, int n, const uint8_t* left, const uint8_t* right,
+                            int width, int height, int16_t* disp) {
+  if (!handles || !left || !right || !disp) return SBM_ERR_NULL;
+  if (n_handles <= 0 || n <= 0) return SBM_ERR_BATCH;
+  for (int k = 0; k < n_handles; k++) {
+    if (!handles[k]) return SBM_ERR_NULL;
+    for (int j = 0; j < k; j++)
+      if (handles[j] == handles[k]) return SBM_ERR_BATCH;   // a handle owns one feed: the same one twice would interleave its staging sets
+  }
+  const size_t npix1 = (size_t)width * height;
+  int first_err = SBM_OK;
+  for (int part = 0; part < 2 && first_err == SBM_OK; part++)
+    for (int k = 0; k < n_handles && first_err == SBM_OK; k++) {
+      const long b0 = (long)n * k / n_handles, b1 = (long)n * (k + 1) / n_handles;   // this engine's block
+      const long half = (b1 - b0 + 1) / 2;
+      const long c0 = part == 0 ? b0 : b0 + half, c1 = part == 0 ? b0 + half : b1;
+      if (c1 <= c0) continue;
+      first_err = sbm_submit_dense(handles[k], (int)(c1 - c0), left + c0 * npix1, right + c0 * npix1, width, height, disp + c0 * npix1);
+    }
+  // drain every engine even after a failure: what was queued writes into `disp`, which the caller may free on return
+  for (int k = 0; k < n_handles; k++) {
+    const int st = sbm_synchronize(handles[k]);
+    if (first_err == SBM_OK) first_err = st;
+  }
+  return first_err;
+}
+
 int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t left_stride, const uint8_t* const* right,
                       size_t right_stride, int width, int height, int16_t* const* disp, size_t disp_stride) {
   if (!h || !left || !right || !disp) return SBM_ERR_NULL;
@@ -1036,10 +1172,12 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
   if (left_stride < (size_t)width || right_stride < (size_t)width || disp_stride < (size_t)width * 2) return SBM_ERR_SIZE;
   for (int i = 0; i < n; i++)
     if (!left[i] || !right[i] || !disp[i]) return SBM_ERR_NULL;
+  HP_BEGIN();
   DeviceScope dscope(h->device);
   HIPCHK(h, dscope.enter());
   st = ensure_staging(h, n, width, height);
   if (st != SBM_OK) return st;
+  HP(0);
   const size_t npix1 = (size_t)width * height;
   // Dense caller images (stride == width, what cv::Mat::isContinuous() gives) go through plain 1-D copies. Strided ones
   // are packed row by row into pinned staging on the CPU: a 2-D copy from pageable memory degenerates into one small
@@ -1076,12 +1214,24 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
     HIPCHK(h, hipMemcpyAsync(h->st_l, pin_l, (size_t)n * npix1, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->st_r, pin_r, (size_t)n * npix1, hipMemcpyHostToDevice, h->stream));
   }
+  HP(1);
   st = sbm_compute_device(h, n, h->st_l, h->st_r, width, height, h->st_d, 0);
   if (st != SBM_OK) return st;
-  if (out_dense) {
+  HP(2);
+  static const int zc_env = env_switch("SBM_HOST_ZEROCOPY", 1);
+  if (out_dense && zc_env && (size_t)n * npix1 * 2 <= ((size_t)8 << 20) && !h->profiling) {
+    // small calls: copy kernel into pinned host memory + flag (see maps_out_kernel), then the rows go to the caller from there
+    st = maps_out_and_wait(h, h->st_d, (size_t)n * npix1);
+    if (st != SBM_OK) return st;
+    HP(3);
+    for (int i = 0; i < n; i++) memcpy(disp[i], h->zc_out + i * npix1, npix1 * 2);
+    HP(4);
+  } else if (out_dense) {
     for (int i = 0; i < n; i++)
       HIPCHK(h, hipMemcpyAsync(disp[i], h->st_d + i * npix1, npix1 * 2, hipMemcpyDeviceToHost, h->stream));
+    HP(3);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HP(4);
   } else {
     HIPCHK(h, hipMemcpyAsync(pin_d, h->st_d, (size_t)n * npix1 * 2, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -46,10 +46,15 @@
 #ifndef SBM_FAST_PINGPONG
 #define SBM_FAST_PINGPONG 0
 #endif
-#ifndef SBM_FAST_HPLAN5   // terms per T of a 5-term window (2: T = V + V', window = T + T'' + V''''; 1: direct)
-#define SBM_FAST_HPLAN5 1
-#endif
 
+// Translation units of this file (the kernel has ~190 instantiations: windows x layouts x exact / masked disparity counts):
+//   SBM_FAST_TU 0  sbm_sad_fast.hip itself: host side + the windows that are multiples of 3 (3-column sums)
+//   SBM_FAST_TU 1  sbm_sad_fast_pw1.hip: the windows 5, 7, 11, 13 (1-column sums), reached through launch_sad_fast_pw1()
+//   SBM_FAST_TU 2  sbm_sad_fast_pw2.hip: the windows 17, 19, 23, 25, reached through launch_sad_fast_pw2()
+//   ping-pong      sbm_sad_fast_pp.hip: the two-accumulator fallback, every window, 64-disparity layouts only
+#ifndef SBM_FAST_TU
+#define SBM_FAST_TU 0
+#endif
 #if SBM_FAST_PINGPONG   // second build of this file (sbm_sad_fast_pp.hip): same kernels with two accumulator arrays
 #define sad_fast_kernel sad_fast_pp_kernel
 #define sad_fast_strip sad_fast_pp_strip
@@ -166,25 +171,26 @@ struct FastLds {
 };
 
 // Plan of the horizontal window sum (LDS-direct strips). The window is NTERM vertical sums V at lane distance KS. Summing
-// them directly costs NTERM - 1 partner reads and (NTERM - 1) / 2 three-operand adds per register; in LEVELS -- T = S1
-// consecutive V, U = S2 consecutive T, every level published to its own exchange area and read back shifted -- the window is
-// NU U's + NTT T's + NVV V's (greedy, left to right): w 21 = T(0) + T(3) + V(6) with T = 3 V: 2 + 2 reads and 2 adds instead of
-// 6 and 3; w 19 (1-column sums) = U(0) + U(9) + V(18): 2 + 2 + 2 reads, 3 adds instead of 18 and 9. The exchange writes
-// double or triple; the LDS pipe has the room (round 4 left it 0.19 busy), the vector unit has none.
+// them directly costs one publish (ds_write_b128), NTERM - 1 partner reads and (NTERM - 1) / 2 three-operand adds per entry of
+// four registers; with an intermediate level -- T = S1 consecutive V, published to a second exchange area and read back
+// shifted -- the window is NTT T's + NVV V's (greedy, left to right): w 21 = T(0) + T(3) + V(6) with T = 3 V: 2 publishes,
+// 2 + 2 reads, 2 adds instead of 1, 6, 3; w 19 (1-column sums) = 6 T + V: 2 publishes, 2 + 6 reads, 4 adds instead of 1, 18, 9.
+// A publish is the expensive part (~25-30 SIMD-cycles in this kernel's mix, more than a v_mqsad_pk_u16_u8: the store path
+// moves address and data registers at 2 cycles per dword and holds the SIMD's register ports -- profiles/r05_sad_isa_budget.md),
+// a partner read ~3.5, an add3 over the entry 19. S1 per window, each measured against its neighbours (KITTI x64 nd 128,
+// profiles/r05_envelope.txt): 5 terms stay direct (a second publish costs more than the add it saves: w 15 0.781 -> 0.841 ms);
+// 7, 9, 11, 13, 19 terms: T = 3 V; 17: T = 4 V; 23, 25: T = 5 V. A third level (U = 3 T) lost everywhere it was tried (w 19:
+// 1.281 against 1.245 ms, w 23: 1.597 against 1.528) and is not in the code.
 #ifndef SBM_FAST_HPLAN   // 0: direct sums everywhere (the round-4 exchange; development builds compare)
 #define SBM_FAST_HPLAN 1
 #endif
 template <int NTERM, int PW>
 struct HPlan {
-  static constexpr int S1 = !SBM_FAST_HPLAN ? 1 : (NTERM >= 7 ? 3 : (NTERM >= 5 ? SBM_FAST_HPLAN5 : 1));
-  static constexpr int S2 = SBM_FAST_HPLAN && NTERM >= 19 ? 3 : 1;
-  static constexpr int SP2 = S1 * S2;                                  // V's under one U
-  static constexpr int NU = S2 > 1 ? NTERM / SP2 : 0;
-  static constexpr int NTT = S1 > 1 ? (NTERM - NU * SP2) / S1 : 0;
-  static constexpr int NVV = NTERM - NU * SP2 - NTT * S1;
-  static constexpr bool PUB1 = S1 > 1 && (S2 > 1 || NTT + (NU > 0) >= 2);   // T is read by other lanes
-  static constexpr bool PUB2 = NU >= 2;                                   // U is read by other lanes
-  static constexpr int NLEV = 1 + PUB1 + PUB2;                            // exchange areas
+  static constexpr int S1 = !SBM_FAST_HPLAN ? 1 : (NTERM >= 23 ? 5 : (NTERM == 17 ? 4 : (NTERM >= 7 ? 3 : 1)));
+  static constexpr int NTT = S1 > 1 ? NTERM / S1 : 0;
+  static constexpr int NVV = NTERM - NTT * S1;
+  static constexpr bool PUB1 = NTT >= 2;            // T is read by other lanes
+  static constexpr int NLEV = 1 + PUB1;             // exchange areas
 };
 // Single-wavefront workgroups stage their rows with LDS-direct loads (see sad_fast_strip): two staged rows per wavefront
 // (entering / leaving), the first one doubling as the exchange area.
@@ -192,42 +198,29 @@ struct HPlan {
 // workgroups per CU. The 64-disparity cooperating wavefronts (5 per SIMD) keep the register-staged strip: two staged rows per
 // wavefront would cost them a workgroup per CU.
 #ifndef SBM_FAST_DMA_ALL
-#define SBM_FAST_DMA_ALL 0
+#define SBM_FAST_DMA_ALL 1
 #endif
-// LDS-direct staging granularity: 1 = single-wavefront workgroups use dword loads into a 4x-expanded layout (slot p = bytes
-// p..p+3) read back with ds_read2_b32 (2: every LDS-direct strip does); 0 = 16-byte loads into the 16x-expanded layout read
-// back with ds_read_b128. A byte-misaligned 16-byte LDS-direct load costs the texture path 64 CU-cycles per wavefront-
-// instruction, a dword one 16 (tools/ubench/lds_dma_rate.hip, profiles/r04_lds_dma_rate.txt): with 10 loads per wavefront-row
-// the 16-byte form kept that path 80 % busy at KITTI size and WAS the bound at 64 disparities and below (KITTI x64 nd 32:
-// 0.733 -> 0.466 ms per step, nd 64: 0.721 -> 0.603, nd 128: 0.960 -> 0.944; 640x480 nd 64 w 21: 0.514 -> 0.489). The two
-// cooperating 128-disparity wavefronts keep the 16-byte form: with twice the window-read instructions they measured +0.4 %.
-#ifndef SBM_FAST_DMA4
-#define SBM_FAST_DMA4 1
-#endif
+// LDS-direct staging is dword-granular: lane i of a load writes bytes i..i+3 of the row piece to dword slot i (the 4x-expanded
+// layout, read back with ds_read2_b32). The 16-byte form into a 16x-expanded layout (round 4's first version) costs the texture path
+// 64 CU-cycles per byte-misaligned wavefront-instruction against 16 (tools/ubench/lds_dma_rate.hip, profiles/r04_lds_dma_rate.txt) and
+// WAS the bound at 64 disparities and below (KITTI x64 nd 32: 0.733 -> 0.466 ms per step, nd 64: 0.721 -> 0.603, nd 128: 0.960 ->
+// 0.944; 640x480 nd 64 w 21: 0.514 -> 0.489). Round 5: the two cooperating 128-disparity wavefronts take the dword form as well
+// (1080p nd 256: 2.012 against 2.014 ms, 2160p: 2.165 against 2.19 -- profiles/r05_nbr_lds_negative.txt, run 2, dev_d2): their staged
+// rows shrink from 5 KB to 1.3 KB, which is what lets the plan's extra exchange level in without costing a workgroup per CU.
 constexpr bool fast_dma(int ndw, int nwaves) { return !SBM_FAST_PINGPONG && (SBM_FAST_DMA_ALL || nwaves == 1 || (ndw == 128 && nwaves == 2)); }
 
-// Neighbour sums S[mind - 1], S[mind + 1] of the LDS-direct strips: 0 = byte-permute selection tree over the registers
-// (NR - 1 v_perm_b32 + selectors: 406 of 3 850 SIMD-cycles per wavefront-row at 128 disparities, profiles/r05_sad_isa_budget.md),
-// 1 = S goes to LDS in NPH phases (NR / 4 ds_write_b128 in all) and every lane fetches its two entries with ds_read_u16.
-#ifndef SBM_FAST_NBR
-#define SBM_FAST_NBR 1
-#endif
 // LDS of one wavefront of an LDS-direct strip, in bytes: two staged-row areas (the first doubles as exchange level 0; 64
-// left-pattern dwords behind each), the further exchange levels of the plan, the S dump of the neighbour look-up.
+// left-pattern dwords behind each) and the further exchange levels of the plan.
 template <int NDW, int NWAVES, int NTERM, int PW, int CS>
 struct DmaLds {
   using L = FastLds<NDW, NTERM, PW, CS>;
   using P = HPlan<NTERM, PW>;
-  static constexpr bool DMA4 = SBM_FAST_DMA4 == 2 || (SBM_FAST_DMA4 == 1 && NWAVES == 1);
-  static constexpr int XCH = DMA4 && L::NQ >= 2 ? 2 : L::XCH;                 // exchange chunk (quads)
-  static constexpr int STAGE_B = DMA4 ? L::NSLOT * 4 : L::NSLOT * 16;       // one staged right row piece
+  static constexpr int XCH = L::NQ >= 2 ? 2 : L::XCH;                       // exchange chunk (quads)
+  static constexpr int STAGE_B = L::NSLOT * 4;                              // one staged right row piece, 4x-expanded (dword slots)
   static constexpr int XLEV_B = ((XCH / 2) * L::XS + (L::XS * 4 + 15) / 16) * 16;   // one exchange level: quad entries + texture column
   static constexpr int PAT_OFS = STAGE_B > XLEV_B ? STAGE_B : XLEV_B;       // the left patterns of a staged row
   static constexpr int AREA_B = PAT_OFS + 256;
-  static constexpr bool NBR = SBM_FAST_NBR && NWAVES == 1 && NDW >= 64;
-  static constexpr int NPH = NDW >= 128 ? 2 : 1;                             // dump phases (NDW / NPH disparities each)
-  static constexpr int DUMP_B = NBR ? (NDW / 2 / NPH) * 256 : 0;                 // [register][lane] dwords of one phase
-  static constexpr int WAVE_B = 2 * AREA_B + (P::NLEV - 1) * XLEV_B + DUMP_B;
+  static constexpr int WAVE_B = 2 * AREA_B + (P::NLEV - 1) * XLEV_B;
 };
 
 // One strip of one row segment of one pair: lane i works on column cbase + CS * i (relative to lofs).
@@ -658,8 +651,8 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
 // LDS-direct load wait for it).
 template <int NDW, int NWAVES, int NTERM, int PW, bool EXACT_ND, int CS>
 __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned char* __restrict__ const b0c, unsigned char* __restrict__ const b1c,
-                                                   unsigned char* __restrict__ const xl1c, unsigned char* __restrict__ const xl2c,
-                                                   unsigned char* __restrict__ const dumpc, u32* __restrict__ const xkey,
+                                                   unsigned char* __restrict__ const xl1c,
+                                                   u32* __restrict__ const xkey,
                                                    const int cbase, const int segi, const int pair) {
   using L = FastLds<NDW, NTERM, PW, CS>;
   using D = DmaLds<NDW, NWAVES, NTERM, PW, CS>;
@@ -673,7 +666,6 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
   constexpr int KS = L::KS;
   constexpr int NV = 64 - KS * (NTERM - 1);   // lanes that produce an output
   constexpr int XCH = D::XCH, XS = L::XS;
-  constexpr bool DMA4 = D::DMA4;        // staging granularity, see SBM_FAST_DMA4
 
   const int lane = threadIdx.x & 63;
   const int wv = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -698,7 +690,6 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
   // texture column sums. Level 0 is b0 after its staged row has been consumed.
   uint4* const xq0 = b0;
   uint4* const xq1 = reinterpret_cast<uint4*>(xl1c);
-  uint4* const xq2 = reinterpret_cast<uint4*>(xl2c);
   auto xt_of = [](uint4* const xq) { return reinterpret_cast<u32*>(xq + (XCH / 2) * XS); };
   const u32 capw = (u32)a.capb * 0x01010101u;
 
@@ -709,19 +700,15 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
   for (int q = 0; q < NQ; q++) VB[q] = 0ull;
   u32 Vt = 0;  // texture: window-row sum of the 3-column |L - cap|
 
-  // buffer_load_dwordx4 ... lds: lane i of load `it` writes its 16 source bytes (row piece bytes 64 it + i .. + 15: a byte-
-  // granular source address is fine, tools/ubench/lds_dma.hip) to LDS slot 64 it + i -- the 16x-expanded layout without a
-  // staging register or a ds_write. The lanes' left patterns follow as 64 dwords at D::PAT_OFS (pat_of()).
+  // buffer_load_dword ... lds: lane i of load `it` writes its 4 source bytes (row piece bytes 64 it + i .. + 3: a byte-granular
+  // source address is fine, tools/ubench/lds_dma.hip) to LDS dword slot 64 it + i -- the 4x-expanded layout without a staging
+  // register or a ds_write. The lanes' left patterns follow as 64 dwords at D::PAT_OFS (pat_of()).
   auto pat_of = [](uint4* const buf) { return reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(buf) + D::PAT_OFS); };
   auto stage = [&](const int y, uint4* const buf) {
     const int rowoff = __builtin_amdgcn_readfirstlane(y * a.pitch);
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      if constexpr (DMA4)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(reinterpret_cast<u32*>(buf) + 64 * it), 4, (int)lane_u, rowoff + 64 * it, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(buf + 64 * it), 16, (int)lane_u, rowoff + 64 * it, 0, 0);
-    }
+    for (int it = 0; it < NIT; it++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(reinterpret_cast<u32*>(buf) + 64 * it), 4, (int)lane_u, rowoff + 64 * it, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (lds_vptr)pat_of(buf), 4, (int)(CS * lane_u), rowoff, 0, 0);
   };
   auto landed = [] {        // everything this wavefront has in flight has landed (LDS-direct loads count in vmcnt)
@@ -742,9 +729,6 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
     constexpr u32 PMASK = PW == 3 ? 0x00ffffffu : 0x000000ffu;
     const u32 pat = pat_of(buf)[lane] & PMASK;  // remaining bytes = 0 -> masked by mqsad
     const u32 tv = __builtin_amdgcn_sad_u8(pat | (capw & ~PMASK), capw, 0u);
-    // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments
-    // (lane stride CS * 16 bytes: 16 consecutive lanes hit 64 distinct banks for CS = 1 and for CS = 3).
-    const uint4* const win_lds = buf + CS * lane;
     auto quad = [&](const int q, const u32 lo, const u32 hi) {
       const u64 win = ((u64)hi << 32) | lo;
       if (!leave) {
@@ -760,7 +744,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
         VB[q] = __builtin_bit_cast(u64, vb);
       }
     };
-    if constexpr (DMA4) {
+    {
       // 4x-expanded staging (dword slot p = bytes p..p+3): the window of quad q is the dword pair (4q, 4q + 4) behind the lane's
       // slot -- one ds_read2_b32 each (lane stride CS dwords: conflict-free for CS = 1 and 3), 16 issued before the first use
       const u32* const win4 = reinterpret_cast<const u32*>(buf) + CS * lane;
@@ -782,41 +766,6 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
             for (int k = 0; k < 4; k++) { lo[k] = win4[4 * (4 * g + k)]; hi[k] = win4[4 * (4 * g + k) + 4]; }
   #pragma unroll
             for (int k = 0; k < 4; k++) quad(4 * g + k, lo[k], hi[k]);
-          }
-        }
-      }
-    } else {
-      // 16 quads (64 disparities) at a time: 4 + 4 ds_read_b128 cover their 17 window dwords in both alignments, all issued before
-      // the first use.
-      if constexpr (EXACT_ND) {
-  #pragma unroll
-        for (int q0 = 0; q0 < NQ; q0 += 16) {
-          constexpr int NM = 4;
-          uint4 ra[NM], rb[NM];
-  #pragma unroll
-          for (int m = 0; m < NM; m++) {
-            ra[m] = win_lds[16 * (q0 / 4 + m)];
-            rb[m] = win_lds[4 + 16 * (q0 / 4 + m)];
-          }
-  #pragma unroll
-          for (int qq = 0; qq < 16 && q0 + qq < NQ; qq++) {
-            // window dwords (qq, qq+1) of this chunk: even qq from ra, odd qq from rb (same bytes shifted by one dword)
-            const uint4 v = (qq & 1) == 0 ? ra[qq >> 2] : rb[(qq - 1) >> 2];
-            quad(q0 + qq, (qq & 2) ? v.z : v.x, (qq & 2) ? v.w : v.y);
-          }
-        }
-      } else {
-        // Disparity counts below the wavefront's NDW (numDisparities is any multiple of 16): group by group (16 disparities), the
-        // groups that do not exist skipped outright -- wavefront-uniform branches, no masked arithmetic. (Batching the chunks that
-        // exist in full as above measured the same: profiles/r04_masked_nd.txt.)
-  #pragma unroll
-        for (int g = 0; g < NQ / 4; g++) {
-          if (16 * g < ndl) {
-            const uint4 ra = win_lds[16 * g], rb = win_lds[4 + 16 * g];
-            quad(4 * g, ra.x, ra.y);
-            quad(4 * g + 1, rb.x, rb.y);
-            quad(4 * g + 2, ra.z, ra.w);
-            quad(4 * g + 3, rb.z, rb.w);
           }
         }
       }
@@ -874,11 +823,18 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
     // sad_fast_strip
     __builtin_amdgcn_s_setprio(SBM_FAST_PRIO_XCH);
     // ---- horizontal window across lanes: S(c + w/2) = sum_k V(c + PW k) through LDS, level by level (HPlan) ---------------
-    // A chunk of XCH quads at a time: publish V, read the S1 - 1 partners of T, publish T, ... ; the last level adds the
-    // remaining T's and V's. Lanes >= NV read entries nobody wrote (halo): their sums are garbage and never stored. The
+    // A chunk of XCH quads at a time: publish V, read the S1 - 1 partners of T, publish T, add the other T's and the remaining V's. Lanes >= NV read entries nobody wrote (halo): their sums are garbage and never stored. The
     // texture column sum takes the same route as a 32-bit column of its own, with the first chunk.
     u32 S[NR];
     unsigned long long tex_ok = 0;
+    // Partner entries are addressed through an OPAQUE copy of the lane index. A lane publishes entry [lane] and reads entries
+    // [lane + k] that only other lanes write; to the optimiser, which sees one thread, a load of [lane + 3] can never be changed
+    // by a store to [lane], and it merged such loads across the chunks of the exchange (a wavefront-scope release fence does
+    // not stop it): with the two-level sums every chunk's T partners came back as the first chunk's (caught by the parity tests
+    // on the cooperating 64-disparity wavefronts). With an index it cannot relate to `lane` every load may alias every store
+    // and stays where it was written; LDS operations of one wavefront execute in order, so nothing else is needed.
+    u32 lx = lane_u;
+    asm volatile("" : "+v"(lx));
     auto add4 = [](u32 (&acc)[4], const uint4 r) { acc[0] += r.x; acc[1] += r.y; acc[2] += r.z; acc[3] += r.w; };   // packed u16 pairs: no carries, every sum stays below 65535
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += XCH) {
@@ -903,10 +859,10 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
 #pragma unroll
         for (int e = 0; e < XCH / 2; e++)
 #pragma unroll
-          for (int k = 1; k < P::S1; k++) add4(A[e], xq0[e * XS + lane + KS * k]);
+          for (int k = 1; k < P::S1; k++) add4(A[e], xq0[e * XS + lx + KS * k]);
         if (tex_now)
 #pragma unroll
-          for (int k = 1; k < P::S1; k++) tA += xt_of(xq0)[lane + KS * k];
+          for (int k = 1; k < P::S1; k++) tA += xt_of(xq0)[lx + KS * k];
         if constexpr (P::PUB1) {
 #pragma unroll
           for (int e = 0; e < XCH / 2; e++) xq1[e * XS + lane] = make_uint4(A[e][0], A[e][1], A[e][2], A[e][3]);
@@ -914,40 +870,21 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
           published();
         }
       }
-      if constexpr (P::S2 > 1) {            // U = S2 consecutive T
-#pragma unroll
-        for (int e = 0; e < XCH / 2; e++)
-#pragma unroll
-          for (int k = 1; k < P::S2; k++) add4(A[e], xq1[e * XS + lane + KS * P::S1 * k]);
-        if (tex_now)
-#pragma unroll
-          for (int k = 1; k < P::S2; k++) tA += xt_of(xq1)[lane + KS * P::S1 * k];
-        if constexpr (P::PUB2) {
-#pragma unroll
-          for (int e = 0; e < XCH / 2; e++) xq2[e * XS + lane] = make_uint4(A[e][0], A[e][1], A[e][2], A[e][3]);
-          if (tex_now) xt_of(xq2)[lane] = tA;
-          published();
-        }
-      }
-      // the window: NU U's, then NTT T's, then NVV V's, left to right; the first term is this lane's own (in A)
+      // the window: NTT T's, then NVV V's, left to right; the first term is this lane's own (in A)
       {
-        constexpr int OT = P::NU * P::SP2, OV = OT + P::NTT * P::S1;   // first T / first V behind the U's / T's
+        constexpr int OV = P::NTT * P::S1;   // first V behind the T's
 #pragma unroll
         for (int e = 0; e < XCH / 2; e++) {
 #pragma unroll
-          for (int u = 1; u < P::NU; u++) add4(A[e], xq2[e * XS + lane + KS * P::SP2 * u]);
+          for (int t = 1; t < P::NTT; t++) add4(A[e], xq1[e * XS + lx + KS * P::S1 * t]);
 #pragma unroll
-          for (int t = (P::NU > 0 ? 0 : 1); t < P::NTT; t++) add4(A[e], xq1[e * XS + lane + KS * (OT + P::S1 * t)]);
-#pragma unroll
-          for (int v = (P::NU + P::NTT > 0 ? 0 : 1); v < P::NVV; v++) add4(A[e], xq0[e * XS + lane + KS * (OV + v)]);
+          for (int v = (P::NTT > 0 ? 0 : 1); v < P::NVV; v++) add4(A[e], xq0[e * XS + lx + KS * (OV + v)]);
         }
         if (tex_now) {
 #pragma unroll
-          for (int u = 1; u < P::NU; u++) tA += xt_of(xq2)[lane + KS * P::SP2 * u];
+          for (int t = 1; t < P::NTT; t++) tA += xt_of(xq1)[lx + KS * P::S1 * t];
 #pragma unroll
-          for (int t = (P::NU > 0 ? 0 : 1); t < P::NTT; t++) tA += xt_of(xq1)[lane + KS * (OT + P::S1 * t)];
-#pragma unroll
-          for (int v = (P::NU + P::NTT > 0 ? 0 : 1); v < P::NVV; v++) tA += xt_of(xq0)[lane + KS * (OV + v)];
+          for (int v = (P::NTT > 0 ? 0 : 1); v < P::NVV; v++) tA += xt_of(xq0)[lx + KS * (OV + v)];
           // the verdict crosses the winner search as a wavefront-uniform mask, not in a vector register
           tex_ok = __ballot((int)tA >= a.tex);
         }
@@ -1051,43 +988,7 @@ __device__ __forceinline__ void sad_fast_strip_dma(const FastArgs& a, unsigned c
     const int ip_ = mind < a.nd - 1 ? mind + 1 : a.nd - 2;
     const int ln = min(max(in_ - d0, 0), NDW - 1), lp = min(max(ip_ - d0, 0), NDW - 1);  // local (clamped) indices
     u32 X0;
-    if constexpr (D::NBR) {
-      // through LDS: S goes out register by register with ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address
-      // VGPR, 2 LDS cycles per wavefront-instruction where a ds_write_b128 costs 13 -- tools/ubench/gen_probe3.py), [register]
-      // [lane] dwords, NPH phases of NR / NPH registers through one area; a lane reads its two entries (local index i: register
-      // i >> 1, half i & 1) in every phase and keeps the one of the right phase. Conflict-free: a lane only touches its column.
-      constexpr int PHR = NR / D::NPH;                     // registers per phase
-      const u32 m0v = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)dumpc);   // (LDS byte address = low half of the flat address)
-      const u32 l4 = lane_u * 4u;
-      const u32 an = ((((u32)ln >> 1) % (u32)PHR) << 8) + (((u32)ln & 1u) << 1) + l4;
-      const u32 ap = ((((u32)lp >> 1) % (u32)PHR) << 8) + (((u32)lp & 1u) << 1) + l4;
-      u32 vn = 0, vp = 0;
-#pragma unroll
-      for (int ph = 0; ph < D::NPH; ph++) {
-        if (ph > 0) reads_done();
-#pragma unroll
-        for (int k = 0; k < PHR; k += 8) {
-          const int j = ph * PHR + k;
-          asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\t"
-                       "ds_write_addtid_b32 %0 offset:%9\n\tds_write_addtid_b32 %1 offset:%9+256\n\t"
-                       "ds_write_addtid_b32 %2 offset:%9+512\n\tds_write_addtid_b32 %3 offset:%9+768\n\t"
-                       "ds_write_addtid_b32 %4 offset:%9+1024\n\tds_write_addtid_b32 %5 offset:%9+1280\n\t"
-                       "ds_write_addtid_b32 %6 offset:%9+1536\n\tds_write_addtid_b32 %7 offset:%9+1792"
-                       :: "v"(S[j]), "v"(S[j + 1]), "v"(S[j + 2]), "v"(S[j + 3]), "v"(S[j + 4]), "v"(S[j + 5]), "v"(S[j + 6]), "v"(S[j + 7]),
-                          "s"(m0v), "n"(k * 256) : "m0", "memory");
-        }
-        published();
-        const u32 rn = *reinterpret_cast<const unsigned short*>(dumpc + an);
-        const u32 rp = *reinterpret_cast<const unsigned short*>(dumpc + ap);
-        if constexpr (D::NPH == 1) {
-          vn = rn; vp = rp;
-        } else {
-          vn = (ln >> 1) / PHR == ph ? rn : vn;
-          vp = (lp >> 1) / PHR == ph ? rp : vp;
-        }
-      }
-      X0 = vn | (vp << 16);
-    } else {
+    {
       // via a byte-permute selection tree
       u32 X[NQ];
       const u32 lnp = (u32)ln | ((u32)lp << 16);
@@ -1204,7 +1105,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     strip = inner;
   }
   // LDS of the workgroup: per wavefront one area of WSLOT slots (staged row / exchange) + the merge area of the workgroup;
-  // LDS-direct strips: per wavefront the areas of DmaLds (two staged rows, further exchange levels, S dump), then the merge area
+  // LDS-direct strips: per wavefront the areas of DmaLds (two staged rows, further exchange levels), then the merge area
   const int wvk = NWAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   unsigned char* const ldsb = reinterpret_cast<unsigned char*>(fast_lds);
   auto dma_strip = [&](auto cs_tag, const int cb) {
@@ -1212,8 +1113,8 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
     using D = DmaLds<NDW, NWAVES, NTERM, PW, CSV>;
     unsigned char* const wb = ldsb + wvk * D::WAVE_B;
     unsigned char* const xl = wb + 2 * D::AREA_B;
-    sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, CSV>(a, wb, wb + D::AREA_B, xl, xl + (D::P::NLEV > 2 ? D::XLEV_B : 0),
-                                                            xl + (D::P::NLEV - 1) * D::XLEV_B, reinterpret_cast<u32*>(ldsb + NWAVES * D::WAVE_B), cb, segi, pair);
+    sad_fast_strip_dma<NDW, NWAVES, NTERM, PW, EXACT_ND, CSV>(a, wb, wb + D::AREA_B, xl,
+                                                            reinterpret_cast<u32*>(ldsb + NWAVES * D::WAVE_B), cb, segi, pair);
   };
   if constexpr (DUAL) {
     constexpr int NV3 = 64 - (NTERM - 1), NV1 = 64 - PW * (NTERM - 1);
@@ -1233,7 +1134,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
   }
 }
 
-#if defined(SBM_DEV_PROF) && !SBM_FAST_PINGPONG
+#if defined(SBM_DEV_PROF) && !SBM_FAST_PINGPONG && SBM_FAST_TU == 0
 // profiling builds: read and clear the border row-loop cycle counters (tools/exp/r04_bwprof.py)
 extern "C" int sbm_dev_bw_prof(unsigned long long* out8) {
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1243,7 +1144,7 @@ extern "C" int sbm_dev_bw_prof(unsigned long long* out8) {
 }
 #endif
 
-#if !SBM_FAST_PINGPONG
+#if !SBM_FAST_PINGPONG && SBM_FAST_TU == 0
 hipError_t launch_sad_fast_pp(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                               int* xa, int* xb, bool border, hipStream_t s);
 
@@ -1333,14 +1234,19 @@ bool sad_fast_supported(const Geom& g) {
   if (xhi - g.w2 + 1 <= g.w2) return false;
   return true;
 }
-#endif  // !SBM_FAST_PINGPONG
+#endif  // !SBM_FAST_PINGPONG && SBM_FAST_TU == 0
+
+// Tuning constants of the border jobs' row segments (chip- and kernel-version specific; they only move time, never results):
+// the launch's expected duration is priced at kBorderModelRate pixel-disparities per second (the interior kernel's rate when
+// the segments were tuned: 3.6e12, profiles/r04_border_bseg.txt), a border row at kBorderRowUs + kBorderColUs per output
+// column (tools/exp/r04_bwprof.py), and a chain may last kBorderChainShare of the launch.
+constexpr double kBorderModelRate = 3.6e12, kBorderRowUs = 2.0, kBorderColUs = 0.25, kBorderChainShare = 0.205;
 
 template <int NDW, int NWAVES, int NTERM, int PW>
 static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   constexpr bool DUAL = PW == 3;
   constexpr int WSLOT1 = FastLds<NDW, NTERM, PW, 1>::WSLOT, WSLOT3 = FastLds<NDW, NTERM, PW, DUAL ? 3 : 1>::WSLOT;
   constexpr int WSLOTM = WSLOT1 > WSLOT3 ? WSLOT1 : WSLOT3;
-  constexpr int NSLOT1 = FastLds<NDW, NTERM, PW, 1>::NSLOT, NSLOT3 = FastLds<NDW, NTERM, PW, DUAL ? 3 : 1>::NSLOT;
   // per wavefront the staged-row / exchange area; then the workgroup's merge area, or -- single-wavefront workgroups with
   // LDS-direct staging -- the second staged-row area
   size_t lds = (size_t)NWAVES * WSLOTM * 16 + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
@@ -1361,9 +1267,9 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
     // w 21 x 64 pairs, where the border columns weigh most: 10 rows per segment 0.520 ms per step, 13 rows 0.537, 6 rows 0.533 --
     // profiles/r04_border_bseg.txt; KITTI x 64 is flat between 32 and 96 rows).
     const int rows = a.row1 - a.row0, wsz = PW * NTERM;
-    const double t_kernel_us = (double)a.npairs * a.W * rows * a.nd / 3.6e12 * 1e6;
-    const double t_row_us = 2.0 + 0.25 * (wsz / 2);
-    int bseg = (int)(0.205 * t_kernel_us / t_row_us - 0.25 * (wsz - 1));
+    const double t_kernel_us = (double)a.npairs * a.W * rows * a.nd / kBorderModelRate * 1e6;
+    const double t_row_us = kBorderRowUs + kBorderColUs * (wsz / 2);
+    int bseg = (int)(kBorderChainShare * t_kernel_us / t_row_us - 0.25 * (wsz - 1));
     bseg = SBM_TUNE("SBM_DEV_BSEG", bseg);
     bseg = std::max(4, std::min(bseg, rows));
     a.nbseg = (rows + bseg - 1) / bseg;
@@ -1376,11 +1282,18 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   dim3 grid((unsigned)(a.bord * a.nbseg + a.strips * a.npairs * a.nseg));
   // development builds: time the border wavefronts alone (results are wrong by construction)
   if (SBM_TUNE("SBM_DEV_BORDER_ONLY", 0)) grid.x = (unsigned)(a.bord * a.nbseg);
+  // (the fallback build only carries the masked-count kernels: they are right for every count up to NDW * NWAVES)
+  // ... and <64,4> only runs one-pair calls beyond 192 disparities: its masked kernel serves 256 as well
+  constexpr bool HAS_EXACT = !SBM_FAST_PINGPONG && !(NDW == 64 && NWAVES == 4);
+  const bool exact = HAS_EXACT && a.nd == NDW * NWAVES;
   snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
-           NDW, NWAVES, NTERM, PW, a.nd == NDW * NWAVES ? "true" : "false", DUAL ? "true" : "false", a.pfshift);
-  if (a.nd == NDW * NWAVES)
-    hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true, DUAL>), grid, dim3(64 * NWAVES), lds, s, a);
-  else
+           NDW, NWAVES, NTERM, PW, exact ? "true" : "false", DUAL ? "true" : "false", a.pfshift);
+  if constexpr (HAS_EXACT) {
+    if (exact) {
+      hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, true, DUAL>), grid, dim3(64 * NWAVES), lds, s, a);
+      return hipGetLastError();
+    }
+  }
     hipLaunchKernelGGL((sad_fast_kernel<NDW, NWAVES, NTERM, PW, false, DUAL>), grid, dim3(64 * NWAVES), lds, s, a);
   return hipGetLastError();
 }
@@ -1391,6 +1304,12 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
 // per wavefront, nd/64 cooperating wavefronts -- the round-1/2 layout, kept for A/B measurements and as the fallback.
 template <int NTERM, int PW>
 static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split, hipStream_t s) {
+#if SBM_FAST_PINGPONG   // the fallback nobody should ever run: correct and reasonably fast, but a quarter of the kernels
+  if (a.nd <= 64) return launch_t<64, 1, NTERM, PW>(a, border, s);
+  if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, border, s);
+  if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, border, s);
+  return launch_t<64, 4, NTERM, PW>(a, border, s);
+#else
   if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, border, s);
   if (a.nd == 48 && SBM_TUNE("SBM_DEV_ND48", 0)) return launch_t<32, 2, NTERM, PW>(a, border, s);   // (rounds 1-3: two 32-disparity wavefronts)
   // one-pair calls: too few workgroups to fill the chip, so split the disparities over two wavefronts (half the serial work
@@ -1407,8 +1326,50 @@ static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split
   if (a.nd <= 128) return launch_t<64, 2, NTERM, PW>(a, border, s);
   if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, border, s);
   return launch_t<64, 4, NTERM, PW>(a, border, s);
+#endif
 }
 
+// the windows that are not multiples of 3 (1-column sums): 5..13 and 17..25, two translation units in the product build
+#if SBM_FAST_TU == 2 || SBM_FAST_PINGPONG || defined(SBM_DEV_FEW19)
+#if SBM_FAST_TU == 2
+hipError_t launch_sad_fast_pw2(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s) {
+#else
+static hipError_t launch_sad_fast_pw2(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s) {
+#endif
+  switch (wsz) {
+#if !defined(SBM_DEV_FEW19)   // (development builds, tools/exp: windows 19 and 23 only)
+    case 17: return launch_nd<17, 1>(a, border, mode, split, s);
+    case 25: return launch_nd<25, 1>(a, border, mode, split, s);
+#endif
+    case 19: return launch_nd<19, 1>(a, border, mode, split, s);
+    case 23: return launch_nd<23, 1>(a, border, mode, split, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#else
+hipError_t launch_sad_fast_pw2(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s);   // sbm_sad_fast_pw2.hip
+#endif
+#if SBM_FAST_TU == 1 || SBM_FAST_PINGPONG || defined(SBM_DEV_FEW19)
+#if SBM_FAST_TU == 1
+hipError_t launch_sad_fast_pw1(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s) {
+#else
+static hipError_t launch_sad_fast_pw1(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s) {
+#endif
+  switch (wsz) {
+#if !defined(SBM_DEV_FEW19)
+    case 5: return launch_nd<5, 1>(a, border, mode, split, s);
+    case 7: return launch_nd<7, 1>(a, border, mode, split, s);
+    case 11: return launch_nd<11, 1>(a, border, mode, split, s);
+    case 13: return launch_nd<13, 1>(a, border, mode, split, s);
+#endif
+    default: return launch_sad_fast_pw2(a, wsz, border, mode, split, s);
+  }
+}
+#elif SBM_FAST_TU == 0
+hipError_t launch_sad_fast_pw1(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s);   // sbm_sad_fast_pw1.hip
+#endif
+
+#if SBM_FAST_TU == 0
 hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                            int* xa, int* xb, bool border, hipStream_t s) {
   *xa = *xb = 0;
@@ -1488,7 +1449,9 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   const bool split = (long)strips * nseg * g.n < 1024 && split_env;
   hipError_t e;
   switch (g.wsz) {
-#ifdef SBM_DEV_FEW   // development builds (tools/exp): only the bench workloads' windows are instantiated
+#if defined(SBM_DEV_FEW19)
+    default: e = launch_sad_fast_pw1(a, g.wsz, border, mode, split, s); break;
+#elif defined(SBM_DEV_FEW)   // development builds (tools/exp): only the bench workloads' windows are instantiated
     case 15: e = launch_nd<5, 3>(a, border, mode, split, s); break;
     case 21: e = launch_nd<7, 3>(a, border, mode, split, s); break;
     default: e = hipErrorInvalidValue; break;
@@ -1497,18 +1460,12 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
     case 15: e = launch_nd<5, 3>(a, border, mode, split, s); break;
     case 21: e = launch_nd<7, 3>(a, border, mode, split, s); break;
     case 27: e = launch_nd<9, 3>(a, border, mode, split, s); break;
-    case 5: e = launch_nd<5, 1>(a, border, mode, split, s); break;
-    case 7: e = launch_nd<7, 1>(a, border, mode, split, s); break;
-    case 11: e = launch_nd<11, 1>(a, border, mode, split, s); break;
-    case 13: e = launch_nd<13, 1>(a, border, mode, split, s); break;
-    case 17: e = launch_nd<17, 1>(a, border, mode, split, s); break;
-    case 19: e = launch_nd<19, 1>(a, border, mode, split, s); break;
-    case 23: e = launch_nd<23, 1>(a, border, mode, split, s); break;
-    default: e = launch_nd<25, 1>(a, border, mode, split, s); break;
+    default: e = launch_sad_fast_pw1(a, g.wsz, border, mode, split, s); break;
 #endif
   }
   *xa = a.xc0; *xb = a.xc1;
   return e;
 }
+#endif  // SBM_FAST_TU == 0
 
 }  // namespace sbm

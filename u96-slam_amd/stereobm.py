@@ -146,6 +146,7 @@ def load_library():
     L.sbm_synchronize.argtypes = [vp]
     L.sbm_submit_dense.argtypes = [vp, ci, vp, vp, ci, ci, vp]
     L.sbm_wait_oldest.argtypes = [vp]
+    L.sbm_compute_batch_multi.argtypes = [ctypes.POINTER(vp), ci, ci, vp, vp, ci, ci, vp]
     L.sbm_debug_fetch.argtypes = [vp, ci, vp, sz]
     L.sbm_set_profiling.argtypes = [vp, ci]
     L.sbm_get_profile.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)]
@@ -307,10 +308,11 @@ class StereoBM:
         if left.shape != right.shape or left.shape != disparity.shape:
             raise StereoBMError(-2, "All the images must have the same size")
         n, h, w = left.shape
-        # the engine drains to at most two outstanding submissions before it queues this one (sbm_submit_dense)
+        # The engine drains to at most two outstanding submissions INSIDE this call, before it queues the new one: only once
+        # it has returned are the oldest submissions' copies known to be complete, so their arrays are released afterwards.
+        _check(self._L.sbm_submit_dense(self._h, n, left.ctypes.data, right.ctypes.data, w, h, disparity.ctypes.data), self._h)
         while len(self._host_inflight) > 2:
             self._host_inflight.popleft()
-        _check(self._L.sbm_submit_dense(self._h, n, left.ctypes.data, right.ctypes.data, w, h, disparity.ctypes.data), self._h)
         self._host_inflight.append((left, right, disparity))
 
     def wait_host(self):
@@ -553,6 +555,23 @@ class StereoBM:
         a = np.empty((n, h, w), dt)
         _check(self._L.sbm_debug_fetch(self._h, which, a.ctypes.data, a.nbytes), self._h)
         return a
+
+
+def compute_multi(engines, left, right, disparity):
+    """sbm_compute_batch_multi: one dense (n,H,W) uint8 host batch over several StereoBM engines (normally one per GPU),
+    contiguous pair blocks, maps delivered into `disparity` (n,H,W) int16 in place. Host memory should be pinned."""
+    for a, dt in ((left, np.uint8), (right, np.uint8), (disparity, np.int16)):
+        if not isinstance(a, np.ndarray) or a.dtype != dt or a.ndim != 3 or not a.flags.c_contiguous:
+            raise StereoBMError(-2, "compute_multi takes C-contiguous (n,H,W) arrays: uint8 images, int16 disparity")
+    if left.shape != right.shape or left.shape != disparity.shape:
+        raise StereoBMError(-2, "All the images must have the same size")
+    if not engines:
+        raise StereoBMError(-24, "compute_multi needs at least one engine")
+    n, h, w = left.shape
+    L = load_library()
+    hs = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    _check(L.sbm_compute_batch_multi(hs, len(engines), n, left.ctypes.data, right.ctypes.data, w, h, disparity.ctypes.data), engines[0]._h)
+    return disparity
 
 
 def trim():
