@@ -45,9 +45,10 @@
  *   SBM_SPECKLE_LISTS   1        per call  0 = row-walking count / apply kernels of the speckle filter; GPU tests
  *   SBM_SPECKLE_BAND    auto     per call  0 / 2 / 4 / 8 = band height of the speckle filter's band walk (0: round-1 kernels);
  *                                          GPU tests
- *   SBM_HOST_ZEROCOPY   1        once      0 = small host-buffer calls (sbm_compute / sbm_compute_batch up to 8 MB of maps) return
- *                                          their maps through a D2H copy + stream synchronisation instead of the copy kernel that
- *                                          writes pinned host memory and raises a flag the host polls; GPU tests / A-B measurements
+ *   SBM_HOST_ZEROCOPY   1        per call  0 = small host-buffer calls (sbm_compute / sbm_compute_batch up to 8 MB of maps) into
+ *                                          pageable memory return their maps through a D2H copy + stream synchronisation instead of
+ *                                          the copy kernel that writes pinned host memory and raises a flag the host polls; GPU
+ *                                          tests / A-B measurements
  * Tuning knobs of the measurement scripts (SBM_FAST_TARGET, SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
  * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*) exist only in development builds (-DSBM_DEV,
  * tools/exp/r04_devlib.sh); this library ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this

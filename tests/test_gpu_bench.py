@@ -161,7 +161,7 @@ def test_async_dense_feed_matches_the_synchronous_call():
 
 
 @pytest.mark.parametrize("env,kernel", [
-    ({"SBM_FAST_INPLACE": "0"}, "sad_fast_pp_kernel<64,2,5,3,true,true> pfshift=2"),      # two-accumulator fallback build (round-2 layout)
+    ({"SBM_FAST_INPLACE": "0"}, "sad_fast_pp_kernel<64,2,5,3,false,true> pfshift=2"),     # two-accumulator fallback build (round-2 layout, masked-count kernels only)
     ({"SBM_FAST_MODE": "0"}, "sad_fast_kernel<64,2,5,3,true,true> pfshift=2"),             # in place, two cooperating wavefronts
     ({"SBM_FAST_PFSHIFT": "0"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),         # unscaled planes, plain key search
     ({"SBM_FAST_PFSHIFT": "1"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),         # w 15 kernels hold the two-bit variant only
@@ -178,7 +178,7 @@ def test_engine_variants_are_bit_exact(env, kernel):
 
 @pytest.mark.parametrize("env,kernel", [
     ({}, "sad_fast_kernel<128,2,7,3,true,true> pfshift=1"),                      # two 128-disparity wavefronts, LDS-direct staging
-    ({"SBM_FAST_MODE": "1"}, "sad_fast_kernel<64,4,7,3,true,true> pfshift=1"),    # four 64-disparity wavefronts, register-staged
+    ({"SBM_FAST_MODE": "1"}, "sad_fast_kernel<64,4,7,3,false,true> pfshift=1"),   # four 64-disparity wavefronts (masked-count kernel: <64,4> has no exact one)
 ])
 def test_256_disparities_both_layouts_are_bit_exact(env, kernel):
     j = _run(["--steps", "2", "--warmup", "1", "--pairs", "4", "--cpu-sample", "2", "--check", "--workload", "fhd", "--prewarm-s", "0"], env=env)

@@ -11,6 +11,15 @@ import pytest
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 
 
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    return torch
+
+
 def _build(tmp_path, pkg):
     exe = tmp_path / "multi_main"
     lib = pkg.library_path()
@@ -120,3 +129,29 @@ def test_two_python_threads_two_engines(pkg, oracle, torch_cuda):
     for t in ts:
         t.join()
     assert not errs, errs[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("zc", ["1", "0"])
+def test_small_host_call_paths_agree(pkg, oracle, torch_cuda, monkeypatch, zc):
+    """sbm_compute on pageable and on pinned caller memory, through the copy kernel + flag (SBM_HOST_ZEROCOPY=1, pageable only)
+    and through the D2H copy: same maps; odd sizes exercise the 2-byte tail of the copy kernel; repeated calls its sequence flag."""
+    from u96_slam_amd import synth
+
+    torch = torch_cuda
+    monkeypatch.setenv("SBM_HOST_ZEROCOPY", zc)
+    for W, H, nd in ((321, 97, 32), (640, 480, 64), (200, 64, 16)):
+        L, R = synth.make_batch(21, 2, W, H, nd)
+        bm = pkg.StereoBM.create(nd, 9)
+        bm.setUniquenessRatio(10); bm.setDisp12MaxDiff(1); bm.setSpeckleWindowSize(30); bm.setSpeckleRange(16)
+        p = oracle.make_params(nd, 9, 31, 0, 10, 10, 30, 16, 1)
+        for rep in range(3):
+            for i in range(2):
+                ref = oracle.compute(p, L[i], R[i])
+                out = np.full((H, W), 12345, np.int16)
+                assert np.array_equal(bm.compute(L[i], R[i], out), ref), (W, H, rep, i, "pageable")
+                pin = torch.full((H, W), 12345, dtype=torch.int16).pin_memory().numpy()
+                assert np.array_equal(bm.compute(L[i], R[i], pin), ref), (W, H, rep, i, "pinned")
+        both = bm.compute(L, R)                       # a two-pair batch through the same entry point
+        for i in range(2):
+            assert np.array_equal(both[i], oracle.compute(p, L[i], R[i]))

@@ -49,7 +49,13 @@ def main():
     shutil.copy(run / "summary_pmc.json", prof / f"{rnd}_kitti_b64_pmc.json")
     if (run / "summary_ref640t_kernels.md").exists():
         shutil.copy(run / "summary_ref640t_kernels.md", prof / f"{rnd}_ref640_b64_kernels.md")
-    for src, dst in (("plain", "plain"), ("trace", "trace"), ("fhd", "fhd"), ("ref640", "ref640"), ("uhd", "uhd")):
+    for tag in ("fhd64", "uhd32", "frontend"):      # BASELINE's own batch sizes; the PL blocks / front-end kernels
+        for suffix in ("kernels.md", "pmc.json"):
+            if (run / f"summary_{tag}_{suffix}").exists():
+                shutil.copy(run / f"summary_{tag}_{suffix}", prof / f"{rnd}_{tag}_{suffix}")
+    if (run / "frontend_kernels.json").exists():
+        shutil.copy(run / "frontend_kernels.json", prof / f"{rnd}_frontend_kernels.json")
+    for src, dst in (("plain", "plain"), ("trace", "trace"), ("fhd", "fhd"), ("ref640", "ref640"), ("uhd", "uhd"), ("fhd64", "fhd64"), ("uhd32", "uhd32")):
         f = run / f"bench_{src}.json"
         if f.exists():
             (prof / f"{rnd}_bench_{dst}.json").write_text(json.dumps(last_json(f)) + "\n")
@@ -66,11 +72,13 @@ def main():
     for wl, pmcfile, benchfile, tag in (("kitti", run / "summary_pmc.json", run / "bench_plain.json", f"{rnd}_kitti_b64_pmc.json"),
                                         ("fhd", run / "summary_fhd_pmc.json", run / "bench_fhd.json", f"{rnd}_fhd_pmc.json"),
                                         ("uhd", run / "summary_uhd_pmc.json", run / "bench_uhd.json", f"{rnd}_uhd_pmc.json"),
-                                        ("ref640", run / "summary_ref640_pmc.json", run / "bench_ref640.json", f"{rnd}_ref640_pmc.json")):
+                                        ("ref640", run / "summary_ref640_pmc.json", run / "bench_ref640.json", f"{rnd}_ref640_pmc.json"),
+                                        ("fhd", run / "summary_fhd64_pmc.json", run / "bench_fhd64.json", f"{rnd}_fhd64_pmc.json"),
+                                        ("uhd", run / "summary_uhd32_pmc.json", run / "bench_uhd32.json", f"{rnd}_uhd32_pmc.json")):
         if not pmcfile.exists() or not benchfile.exists():
             continue
         pmc = json.loads(pmcfile.read_text())
-        if wl != "kitti":
+        if wl != "kitti" and pmcfile.resolve() != (prof / tag).resolve():
             shutil.copy(pmcfile, prof / tag)
         bench = last_json(benchfile)
         B = bench["config"]["pairs_per_gpu_per_step"]
