@@ -155,3 +155,31 @@ def test_small_host_call_paths_agree(pkg, oracle, torch_cuda, monkeypatch, zc):
         both = bm.compute(L, R)                       # a two-pair batch through the same entry point
         for i in range(2):
             assert np.array_equal(both[i], oracle.compute(p, L[i], R[i]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(400, 90, 128, 15, 3, 0), (640, 120, 64, 21, 1, 0), (420, 80, 112, 15, 5, 0), (500, 90, 192, 21, 2, 0),
+                                   (400, 90, 128, 19, 2, 0), (640, 120, 256, 21, 2, 0), (360, 80, 48, 11, 1, -8), (400, 90, 64, 27, 3, 4)])
+def test_filtered_pixels_store_cost_ffff(pkg, torch_cuda, shape):
+    """The range-test-free path of lrcheck16_kernel relies on an invariant that spans files: every producer of the
+    16-bit cost plane -- LDS-direct strips of every layout, border wavefronts -- stores cost 0xffff with every FILTERED pixel
+    of the computed region [lofs, lofs + xend) x [row0, row1) and real costs <= 65534. Checked directly here, not through a
+    downstream mismatch: single-wavefront, cooperating, masked-count and one-pair (split) layouts, 1- and 3-column sums."""
+    from u96_slam_amd import synth
+
+    W, H, nd, w, n, mind = shape
+    L, R = synth.make_batch(31, n, W, H, nd)
+    bm = pkg.StereoBM.create(nd, w)
+    bm.setMinDisparity(mind); bm.setUniquenessRatio(10); bm.setTextureThreshold(10); bm.setDisp12MaxDiff(1)
+    bm.compute(L, R)
+    pre = bm.debug_fetch(3, n, H, W)
+    cost = bm.debug_fetch(2, n, H, W)
+    filtered = (mind - 1) * 16
+    lofs, rofs = max(nd - 1 + mind, 0), -min(nd - 1 + mind, 0)
+    xend = min(W - rofs - nd + 1, W - lofs)
+    w2 = w // 2
+    region = (slice(None), slice(w2, H - w2), slice(lofs, lofs + xend))
+    p, c = pre[region], cost[region]
+    assert bm.last_kernel().startswith("sad_fast_kernel"), bm.last_kernel()
+    assert ((p == filtered) == (c == 0xFFFF)).all(), (int(((p == filtered) & (c != 0xFFFF)).sum()), int(((p != filtered) & (c == 0xFFFF)).sum()))
+    assert (c[p != filtered] <= 65534).all() and (p != filtered).mean() > 0.2

@@ -78,7 +78,7 @@ struct FastArgs {
   int W, H, pitch, padl, plane;
   int nd, mindisp, lofs, rofs, tex, uniq, filtered, capb;
   int row0, row1;            // rows [row0,row1)
-  int segrow[34];            // row segment k = rows [segrow[k], segrow[k+1]); long segments first, short ones last
+  int segrow[66];            // row segment k = rows [segrow[k], segrow[k+1]); long segments first, short ones last
   int strips, nseg, npairs;  // grid decomposition (1-D grid of strips*nseg*npairs workgroups)
   int strips3;               // the first strips3 strips (a multiple of 3) have column stride 3, the others stride 1
   int uniq_plain;            // 8 * (maxS * uniq / 100 + 1) fits 16 bits: deficit partial sums need no saturating adds
@@ -1416,12 +1416,16 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 3 * g.wsz) nseg++;
   // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
   // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
-  while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= g.wsz && nseg < 32) nseg++;
+  // (round 5: down to 8 rows per segment and up to 64 segments -- a one-pair launch is a chain of rows per wavefront, and
+  // w - 1 priming rows at a third of a row's cost are cheaper than idle SIMDs: one 640x480 nd 64 w 21 pair 0.054 -> 0.049 ms,
+  // one KITTI pair 0.052 -> 0.036, one 1080p nd 256 pair 0.221 -> 0.188; profiles/r05_small_launch_segments.txt)
+  static const int small_rows = SBM_TUNE("SBM_DEV_SMALL_ROWS", 8);
+  while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= small_rows && nseg < 64) nseg++;
   static const int nseg_env = SBM_TUNE("SBM_FAST_NSEG", 0);
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
   // taper: the last third of the rows is cut into segments of 2/3, 1/2, 1/3 ... of the regular length
   static const int taper = SBM_TUNE("SBM_FAST_TAPER", 1);
-  nseg = std::min(nseg, 32);
+  nseg = std::min(nseg, 64);
   int ns = 0;
   a.segrow[0] = g.row0;
   if (!taper || nseg < 3) {
