@@ -1414,13 +1414,25 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   static const long target_env = SBM_TUNE("SBM_FAST_TARGET", 0);
   const long target = target_env > 0 ? target_env : (g.nd > 128 ? 5600L : 24000L);
   while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 3 * g.wsz) nseg++;
-  // small batches (the reference's one-pair-per-call pattern) leave most of the chip idle: there latency matters, not
-  // the priming overhead, so keep cutting until every SIMD has a wavefront or segments reach one window height
-  // (round 5: down to 8 rows per segment and up to 64 segments -- a one-pair launch is a chain of rows per wavefront, and
-  // w - 1 priming rows at a third of a row's cost are cheaper than idle SIMDs: one 640x480 nd 64 w 21 pair 0.054 -> 0.049 ms,
-  // one KITTI pair 0.052 -> 0.036, one 1080p nd 256 pair 0.221 -> 0.188; profiles/r05_small_launch_segments.txt)
+  // Launches that do not fill the chip (round 5, profiles/r05_small_launch_segments.txt): a wavefront's row segment is a serial
+  // chain, and w - 1 priming rows at a third of a row's cost are cheaper than idle SIMDs -- segments go down to 8 rows (up to
+  // 64 of them) until the launch has ~5 000 workgroups. Launches that cannot even reach ~1 800 wavefronts that way (one or two
+  // pairs) split the disparities over more wavefronts per workgroup instead (launch_nd: `split`) and take as many segments
+  // as keep them under 1 024 workgroups. One 640x480 nd 64 w 21 pair: SAD stage 0.054 -> 0.049 ms, one KITTI pair 0.052 ->
+  // 0.036, 8 KITTI pairs 0.209 -> 0.14, 16 pairs 640x480 0.203 -> 0.12, 4 pairs 1080p nd 256 0.64 -> 0.57.
   static const int small_rows = SBM_TUNE("SBM_DEV_SMALL_ROWS", 8);
-  while ((long)strips * nseg * g.n < 1024 && rows / (nseg + 1) >= small_rows && nseg < 64) nseg++;
+  static const long fill = SBM_TUNE("SBM_DEV_FILL", 5000);
+  const int maxseg = std::max(nseg, std::min(64, rows / small_rows));
+  const long per_seg = (long)strips * g.n;
+  if (per_seg * maxseg * (g.nd > 128 ? 2 : 1) < 1800) {
+    nseg = std::max(nseg, (int)std::min<long>(maxseg, 1023 / per_seg));
+  } else {
+    const int nseg1 = nseg;
+    while (per_seg * nseg < fill && nseg < maxseg) nseg++;
+    // (two cooperating 128-disparity wavefronts: 1 536 workgroups are one round of the chip; a launch that ends between 1 and
+    // 1.5 rounds pays a second, mostly empty round -- one 1080p nd 256 pair: 64 segments 0.204 ms, 36..48 segments 0.189..0.196)
+    if (g.nd > 128 && per_seg * nseg > 1536 && per_seg * nseg < 2304) nseg = std::max(nseg1, (int)(1450 / per_seg));
+  }
   static const int nseg_env = SBM_TUNE("SBM_FAST_NSEG", 0);
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));
   // taper: the last third of the rows is cut into segments of 2/3, 1/2, 1/3 ... of the regular length
