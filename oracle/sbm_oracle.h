@@ -20,6 +20,17 @@
  *   * Block-matching output (SAD/WTA/uniqueness/LR/speckle): PARITY UNPINNED -- the reference holds no
  *     golden disparity map and OpenCV cannot be built or imported in this environment. The restatement
  *     is cross-checked only against an independent brute-force evaluation of the same definitions.
+ *     Recall risks (SURVEY.md A.7 and one more), each with a case in the pin kit (tests/golden/pin_kit.npz,
+ *     tools/verify_with_opencv.py settles them on any box with OpenCV):
+ *       1. speckleRange is compared unscaled (1/16 px units) by filterSpeckles for BM output;
+ *       2. the BM cost plane is `short` in OpenCV: sums above 32767 (w^2 * 2 * cap) wrap there, not here;
+ *       3. odd image height: the last prefilter row is `cap`;
+ *       4. validateDisparity: strict '>' claim, minX1 = max(minD + nd, 0) start column;
+ *       5. IPP builds may route filterSpeckles through IPP (claimed identical);
+ *       6. non-empty ROI1 / ROI2 change the valid ROI;
+ *       7. getValidDisparityROI: the 2.4 lineage subtracts minDisparity in xmax (roi2.x + roi2.width - minD),
+ *          this restatement follows 4.x and does not -- invisible at minDisparity 0 (the reference's call site
+ *          and every BASELINE config), decides the right border otherwise.
  */
 #ifndef SBM_ORACLE_H_
 #define SBM_ORACLE_H_
