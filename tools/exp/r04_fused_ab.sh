@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: needs commit f8c40e8 (the last one that still has the SBM_BORDER_FUSED switch and the side-stream border kernel); on later trees both runs take the same path.
 # round 4: the border columns inside the interior launch (SBM_BORDER_FUSED=1, default) against the round-3 border kernel on
 # the side stream (=0), alternating, bit-exact check on, per workload.  usage: tools/exp/r04_fused_ab.sh [workloads...]
 WLS=${@:-kitti ref640 fhd uhd}

@@ -297,8 +297,13 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      // (other lanes' entries are read through an opaque copy of the lane index: to the optimiser a load of [lane] cannot be
+      // changed by this lane's store to [1 + lane], and it would be free to merge it with the previous phase's load of the
+      // same address -- see sad_fast_strip_dma, round 5)
+      int lxo = lane;
+      asm volatile("" : "+v"(lxo));
 #pragma unroll
-      for (int q = 0; q < FP_NR; q++) S[q] = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz] - xrow[q * FP_XS + lane];
+      for (int q = 0; q < FP_NR; q++) S[q] = xrow[q * FP_XS + 1 + lxo + 2 * a.hwsz] - xrow[q * FP_XS + lxo];
       __builtin_amdgcn_s_setprio(0);
 
       if (sample) {
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
         // neighbours of the winner lane jw = i1 + 1: lanes jw - 1 and jw + 1, looked up in the prefix rows
         auto sad_of_lane = [&](int j) -> u32 {
           const int q = (34 - j) >> 1, hi = (34 - j) & 1;   // lane 34-2q is the low half
-          const u32 pa = xrow[q * FP_XS + 1 + lane + 2 * a.hwsz], pb = xrow[q * FP_XS + lane];
+          const u32 pa = xrow[q * FP_XS + 1 + lxo + 2 * a.hwsz], pb = xrow[q * FP_XS + lxo];
           const u32 d = pa - pb;
           return hi ? (d >> 16) : (d & 0xffffu);
         };

@@ -397,6 +397,10 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
     // (ds_bpermute_b32 would do the same without the round trip, but it costs ~24 SIMD-cycles per 4 bytes/lane on
     // gfx950 -- measured with tools/ubench/isa_probe -- which made the kernel crossbar-bound.)
     // Lanes >= NV read beyond lane 63 (unwritten halo entries): their sums are garbage and never stored.
+    // (partner entries through an opaque copy of the lane index, as in sad_fast_strip_dma: a load of [lane + k] must not be
+    // merged with the previous chunk's load of the same address -- only OTHER lanes write it)
+    u32 lx = lane_u;
+    asm volatile("" : "+v"(lx));
     u32 S[NR];
     const int par = y & 1;
     const int orow = __builtin_amdgcn_readfirstlane(2 * y * a.W);
@@ -417,7 +421,7 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
         u32 s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
 #pragma unroll
         for (int k = 1; k < NTERM; k++) {
-          const uint4 r = xq[(qq / 2) * XS + lane + KS * k];
+          const uint4 r = xq[(qq / 2) * XS + lx + KS * k];
           s0 += r.x;               // packed u16 pairs: no carries, every sum stays below 65535
           s1 += r.y;
           s2 += r.z;
@@ -592,7 +596,7 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
     if (mine) {
       int tsum = (int)Vt;
 #pragma unroll
-      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lane + KS * k];
+      for (int k = 1; k < NTERM; k++) tsum += (int)xt[lx + KS * k];
       bool ok = tsum >= a.tex;
       // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
       if (a.uniq > 0) {
