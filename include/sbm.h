@@ -49,7 +49,7 @@
  *                                          pageable memory return their maps through a D2H copy + stream synchronisation instead of
  *                                          the copy kernel that writes pinned host memory and raises a flag the host polls; GPU
  *                                          tests / A-B measurements
- * Tuning knobs of the measurement scripts (SBM_FAST_TARGET, SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
+ * Tuning knobs of the measurement scripts (SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
  * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*) exist only in development builds (-DSBM_DEV,
  * tools/exp/r04_devlib.sh); this library ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this
  * library inside u96-slam_amd/lib/, A-B measurements only); bench.py reads SBM_BENCH_BACKEND / SBM_BENCH_FEED /

@@ -13,7 +13,7 @@ namespace sbm {
 //   env_switch(): read in every build. They select a tested fallback or a code path that the GPU tests compare with the
 //                 default one: SBM_FAST_INPLACE, SBM_FAST_MODE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS,
 //                 SBM_SPECKLE_BAND, SBM_HOST_ZEROCOPY.
-//   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_TARGET, SBM_FAST_NSEG, SBM_FAST_TAPER,
+//   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_NSEG, SBM_FAST_TAPER,
 //                 SBM_FAST_UNIQ_PLAIN, SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*): compiled in
 //                 only with -DSBM_DEV (the development library of tools/exp/r04_devlib.sh); the product ignores them.
 inline int env_switch(const char* name, int dflt) {

@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <type_traits>
 
@@ -1406,18 +1407,23 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   const int rem = std::max(0, ncols - triples * 3 * nv3);
   const int strips = a.strips3 + (rem + nv - 1) / nv;
   const int rows = g.row1 - g.row0;
-  // row segments: enough wavefronts to fill 256 CUs several times over, but keep the priming overhead (w-1 rows per
-  // segment at ~1/3 of a full row's cost) below ~10 %. The target is tuned on the length of the whole SAD stage, interior
-  // kernel + what remains of the border kernel after it: fewer, longer interior workgroups cost the interior kernel ~1 %
-  // but let the border kernel finish earlier (KITTI x64, 4 instead of 6 segments: 1.100 + 0.053 -> 1.115 + 0.028 ms;
-  // tools/exp/r02_target.sh: 5600 is never worse than 9000 or 4500 on any of the bench workloads)
+  // Row segments. Every segment pays w - 1 priming rows (~0.2 of a full row each: mqsad only); few long segments keep that low,
+  // many short ones keep the tail of the launch short (the last, partly empty round of workgroups). With R rounds of the chip
+  // the two costs are ~ prime * nseg / rows and ~ c / R, R = strips * pairs * nseg / slots, so the optimum is
+  //   nseg = sqrt(c * slots * rows / (strips * pairs * prime)),   slots = workgroups the chip holds at once for the layout
+  // (4 096 / 3 072 / 1 536 at up to 64 / 128 / 256 disparities), c = 0.196 fitted on the forced-count sweeps of round 5
+  // (profiles/r05_small_launch_segments.txt, last table: KITTI x64 best at 8 = the formula's 8.0; 640x480 nd 64 w 21 x64 best at
+  // 10-14, formula 12, round 4's rule 6: 0.476 -> 0.469 ms; 1080p nd 256 x64 best 6-8, formula 6.6, round 4's 4: 8.28 -> 8.19;
+  // 2160p x32 best 8-12, formula 9, round 4's 3: 17.64 -> 16.97; 1080p x16 and 2160p x4 unchanged at 13 and 25). Round 4's rule
+  // (a workgroup target of 24 000 / 5 600 with segments of at least three window heights) was tuned at 64 / 16 / 4 pairs only.
   int nseg = 1;
-  // Round 4: with the border columns inside this launch (no second kernel whose tail grows with the segment count) finer
-  // segments pay where one wavefront is a workgroup: KITTI x64 1.099 -> 1.081 ms per step at 11 000 - 32 000 (flat), 640x480
-  // flat, the cooperating-wavefront kernels (nd > 128) best at 4 000 - 5 600 (profiles/r04_border_fused_sweep*.txt)
-  static const long target_env = SBM_TUNE("SBM_FAST_TARGET", 0);
-  const long target = target_env > 0 ? target_env : (g.nd > 128 ? 5600L : 24000L);
-  while ((long)strips * nseg * g.n < target && rows / (nseg + 1) >= 3 * g.wsz) nseg++;
+  {
+    const double prime = 0.2 * (g.wsz - 1);
+    const double slots = g.nd <= 64 ? 4096.0 : (g.nd <= 128 ? 3072.0 : 1536.0);
+    static const int c1000 = SBM_TUNE("SBM_DEV_SEG_C", 196);
+    nseg = (int)(std::sqrt(c1000 * 1e-3 * slots * rows / ((double)strips * g.n * prime)) + 0.5);
+    nseg = std::max(1, std::min(nseg, std::max(1, rows / g.wsz)));   // (at least one window height per segment here; see below)
+  }
   // Launches that do not fill the chip (round 5, profiles/r05_small_launch_segments.txt): a wavefront's row segment is a serial
   // chain, and w - 1 priming rows at a third of a row's cost are cheaper than idle SIMDs -- segments go down to 8 rows (up to
   // 64 of them) until the launch has ~5 000 workgroups. Launches that cannot even reach ~1 800 wavefronts that way (one or two
