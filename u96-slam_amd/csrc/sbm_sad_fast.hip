@@ -1285,6 +1285,9 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
     a.nbseg = 0;
   }
   dim3 grid((unsigned)(a.bord * a.nbseg + a.strips * a.npairs * a.nseg));
+  if (SBM_TUNE("SBM_DEV_PRINT", 0))   // development builds: the launch geometry
+    fprintf(stderr, "[sbm] <%d,%d,%d,%d> strips %d (cs3 %d) nseg %d pairs %d bord %d x %d grid %u lds %zu\n", NDW, NWAVES, NTERM, PW, a.strips, a.strips3,
+            a.nseg, a.npairs, a.bord, a.nbseg, grid.x, lds);
   // development builds: time the border wavefronts alone (results are wrong by construction)
   if (SBM_TUNE("SBM_DEV_BORDER_ONLY", 0)) grid.x = (unsigned)(a.bord * a.nbseg);
   // (the fallback build only carries the masked-count kernels: they are right for every count up to NDW * NWAVES)
