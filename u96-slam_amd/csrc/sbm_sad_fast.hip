@@ -12,15 +12,21 @@
 //               H3(c,y,d) = sum_{i<3} |Lp[y][c+i] - Rp[y][c+i-D]|, packed 4 x u16 per VGPR pair.
 //               One v_mqsad_pk_u16_u8 produces H3 for 4 consecutive disparities AND accumulates (pattern = 3 left
 //               bytes + a zero byte, which the instruction masks; sliding 8-byte window = right bytes).
-//               Entering row: VB = mqsad(R, L, VA).  Leaving row: VA = VB - mqsad(R, L, 0)  (dst may not alias a source).
-//   LDS       = the right row piece of the wavefront, expanded 16x (slot p holds bytes p..p+15) so that every lane's
-//               16-byte-aligned ds_read_b128 stream starts at its own byte offset; conflict-free (lane stride 16 B).
+//               Entering row: V = mqsad(R, L, V), accumulated IN PLACE (vdst == src2: right on gfx950, checked by a device
+//               self-test; sbm_sad_fast_pp.hip is the two-array fallback).  Leaving row: V -= mqsad(R, L, 0).
+//   LDS       = the right row piece of the wavefront, staged by LDS-direct loads (buffer_load_dword ... lds: no staging
+//               registers) into a 4x-expanded layout -- dword slot p holds bytes p..p+3, so a quad's 8-byte window is the
+//               dword pair (4q, 4q+4) behind the lane's slot, one conflict-free ds_read2_b32 (sad_fast_strip_dma: every
+//               layout since round 5). The register-staged strip with its 16x-expanded layout (sad_fast_strip) remains for
+//               the fallback build.
 //   exchange  = horizontal window: S(c + w/2) = sum_k V(c + 3k), k < w/3: lanes publish V to LDS ([quad pair][lane],
-//               16 B entries) and read the shifted copies back (conflict-free b128 traffic); lanes whose partners fall
-//               outside the wavefront (the last w-3) produce nothing and are recomputed by the next strip.
-//   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan),
-//               uniqueness by a saturating deficit sum, S[mind +- 1] by a v_perm_b32 selection tree; per-wavefront
-//               results merged through LDS, one wavefront (alternating per row) finishes and stores.
+//               16 B entries) and read the shifted copies back; from 7 terms on in two levels (HPlan: T = a few V,
+//               published again, window = a few T + the remaining V). Lanes whose partners fall outside the wavefront
+//               produce nothing and are recomputed by the next strip.
+//   WTA       = in registers: min over (S << 16 | d) keys (first d wins ties, as cv's strict '<' scan; a tagged packed
+//               search on pre-scaled planes where the sums leave bits free), uniqueness by a saturating deficit sum,
+//               S[mind +- 1] by a v_perm_b32 selection tree; per-wavefront results merged through LDS, one wavefront
+//               (alternating per row) finishes and stores.
 // Column stride (template parameter CS, windows that are multiples of 3): with CS = 3 lane i takes column base + 3 i, so the
 // partners of the horizontal window V(c), V(c+3), ... are the NEXT LANES and only NTERM - 1 lanes of a wavefront produce
 // nothing (w 15: 60 of 64 lanes useful instead of 52; w 21: 58 instead of 46). Three such wavefronts (bases b, b+1, b+2)
@@ -193,11 +199,11 @@ struct HPlan {
   static constexpr bool PUB1 = NTT >= 2;            // T is read by other lanes
   static constexpr int NLEV = 1 + PUB1;             // exchange areas
 };
-// Single-wavefront workgroups stage their rows with LDS-direct loads (see sad_fast_strip): two staged rows per wavefront
-// (entering / leaving), the first one doubling as the exchange area.
-// ... and so do two cooperating 128-disparity wavefronts (129..256 disparities): 2 x 2 areas + the merge area still leave six
-// workgroups per CU. The 64-disparity cooperating wavefronts (5 per SIMD) keep the register-staged strip: two staged rows per
-// wavefront would cost them a workgroup per CU.
+// Every layout stages its rows with LDS-direct loads (sad_fast_strip_dma): two staged rows per wavefront (entering / leaving),
+// the first one doubling as exchange level 0. Round 4 kept the register-staged strip for the 64-disparity cooperating
+// wavefronts (two 16x-expanded staged rows per wavefront cost them a workgroup per CU); with dword staging the areas are a
+// quarter of that and the LDS-direct strip wins there too (1080p nd 192: 1.88 -> 1.65 ms, one 1080p pair: 0.248 -> 0.190).
+// SBM_FAST_DMA_ALL=0 (development builds): single-wavefront workgroups and the two 128-disparity wavefronts only.
 #ifndef SBM_FAST_DMA_ALL
 #define SBM_FAST_DMA_ALL 1
 #endif
@@ -641,16 +647,14 @@ __device__ __forceinline__ void sad_fast_strip(const FastArgs& a, const int cbas
   }
 }
 
-// The same strip for single-wavefront workgroups, with LDS-DIRECT STAGING (round 4): the right row pieces go from HBM / L2
-// straight into the 16x-expanded LDS layout (buffer_load_dwordx4 ... lds: lane i's 16 source bytes land in slot i), so a row in
-// flight costs no registers (21 VGPRs per row before, two rows in flight at the kernel's pressure peak) and no ds_write_b128
-// (10 per wavefront-row at KITTI size, 16 % of the kernel's LDS-pipe cycles). Two staged-row areas per wavefront: b0 takes the
-// entering row and, once that is consumed, serves as the exchange area; b1 takes the leaving row. Both rows are consumed at
-// the TOP of an output row (leave, then enter), so both areas are free for the rest of the row and the next rows' loads have
-// a whole row to arrive; one s_waitcnt vmcnt(0) per row. A row's results are stored one iteration late, behind that wait.
-// KITTI x64 (same box, alternating, bit-exact): SAD stage 0.910 -> 0.801 ms, step 1.083 -> 0.976 ms; 168 -> 165 VGPRs, 12 -> 0
-// bytes of scratch. The cooperating-wavefront kernels (nd > 128) keep the register-staged strip above: two staged rows per
-// wavefront would cost them a workgroup per CU (LDS).
+// The strip with LDS-DIRECT STAGING (round 4; every layout of the product build since round 5): the right row pieces go from
+// HBM / L2 straight into the expanded LDS layout (buffer_load_dword ... lds: lane i's source bytes land in dword slot i), so a
+// row in flight costs no registers (21 VGPRs per row before, two rows in flight at the kernel's pressure peak) and no
+// ds_write_b128 (10 per wavefront-row at KITTI size). Two staged-row areas per wavefront: b0 takes the entering row and, once
+// that is consumed, serves as exchange level 0; b1 takes the leaving row. Both rows are consumed at the TOP of an output row
+// (leave, then enter), so both areas are free for the rest of the row and the next rows' loads have a whole row to arrive; one
+// s_waitcnt vmcnt(0) per row. A row's results are stored one iteration late, behind that wait. KITTI x64 (same box,
+// alternating, bit-exact): SAD stage 0.910 -> 0.801 ms with the 16-byte form, 0.777 with the dword form; no scratch.
 // b0 / b1: the wavefront's LDS areas, `restrict` so that the scoped no-alias information lets LDS traffic of one area run
 // while LDS-direct loads into the other are in flight (the compiler makes every LDS access that MAY alias a pending
 // LDS-direct load wait for it).
