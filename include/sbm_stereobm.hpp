@@ -18,6 +18,8 @@
 #include <stdexcept>
 #include <string>
 
+#include <vector>
+
 #include "sbm.h"
 
 #if defined(SBM_WITH_OPENCV) || (defined(__has_include) && __has_include(<opencv2/core.hpp>))
@@ -102,6 +104,17 @@ class StereoBM {
 #endif
 
   sbm_handle* handle() const { return h_; }
+
+  // One dense host batch (n*height*width bytes per side, n*height*width int16 out, pinned memory recommended) over several
+  // matchers -- normally one per GPU, created with create(nd, bs, device): contiguous pair blocks, every device busy at once
+  // from this one thread (sbm_compute_batch_multi; INTEGRATION.md "Several GPUs from one C++ process").
+  static void computeBatch(const std::vector<std::shared_ptr<StereoBM>>& matchers, int n, const uint8_t* left, const uint8_t* right,
+                           int width, int height, int16_t* disp) {
+    std::vector<sbm_handle*> hs;
+    for (const auto& m : matchers) hs.push_back(m ? m->h_ : nullptr);
+    const int st = sbm_compute_batch_multi(hs.data(), (int)hs.size(), n, left, right, width, height, disp);
+    if (st != SBM_OK) throw Error(st, sbm_strerror(st));
+  }
 
  private:
   StereoBM(int nd, int bs, int device) : h_(nullptr) {

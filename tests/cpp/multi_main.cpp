@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "sbm.h"
+#include "sbm_stereobm.hpp"
 
 static bool read_all(const char* path, void* buf, size_t bytes) {
   FILE* f = std::fopen(path, "rb");
@@ -102,6 +103,26 @@ int main(int argc, char** argv) {
     }
     for (sbm_handle* h : hs) sbm_destroy(h);
     std::printf("multi: %d device(s) x %d handle(s)\n", ndev, per_dev);
+  }
+  // --- the same through the C++ adaptor: one sbm::StereoBM per device, StereoBM::computeBatch -----------------------------------
+  {
+    std::vector<std::shared_ptr<sbm::StereoBM>> ms;
+    for (int d = 0; d < ndev; d++) {
+      auto bm = sbm::StereoBM::create(16, 9, d);                     // main.cpp:201-212
+      bm->setPreFilterCap(31); bm->setBlockSize(21); bm->setMinDisparity(0); bm->setNumDisparities(64); bm->setTextureThreshold(10);
+      bm->setUniquenessRatio(10); bm->setSpeckleWindowSize(50); bm->setSpeckleRange(32); bm->setDisp12MaxDiff(1);
+      ms.push_back(bm);
+    }
+    int16_t* pin3 = nullptr;
+    if (hipHostMalloc((void**)&pin3, npix * N * 2, 0) != hipSuccess) return 4;
+    try {
+      sbm::StereoBM::computeBatch(ms, N, left, right, W, H, pin3);
+    } catch (const sbm::Error& e) {
+      std::fprintf(stderr, "computeBatch: %s\n", e.what());
+      return 14;
+    }
+    if (std::memcmp(pin3, d_multi, npix * N * 2) != 0) { std::fprintf(stderr, "adaptor batch differs\n"); return 15; }
+    (void)hipHostFree(pin3);
   }
   // --- two host threads, two handles on device 0, one pair per call -----------------------------------------------------------
   {
