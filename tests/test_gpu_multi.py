@@ -81,6 +81,12 @@ def test_compute_multi_blocks_python(pkg, oracle, torch_cuda):
                 assert np.array_equal(out[i], oracle.compute(p, L[i], R[i])), (k, i)
     with pytest.raises(pkg.StereoBMError):
         pkg.compute_multi([engines[0], engines[0]], Lp, Rp, out)
+    # fewer pairs than engines: the first engines get empty blocks, the last one the pair
+    one = torch.empty((1, H, W), dtype=torch.int16).pin_memory().numpy()
+    pkg.compute_multi(engines, Lp[:1], Rp[:1], one)
+    bm = engines[-1]
+    p = oracle.make_params(bm.getNumDisparities(), bm.getBlockSize(), 31, 0, 10, 10, 30, 16, 1)
+    assert np.array_equal(one[0], oracle.compute(p, L[0], R[0]))
 
 
 @pytest.mark.gpu
