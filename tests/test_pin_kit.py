@@ -69,3 +69,51 @@ def test_kit_covers_the_risk_list(kit):
     assert not np.array_equal(kit["ref_pair_w21_callsite/s1_uniq"], kit["ref_pair_w21_callsite/s0_wta"])
     assert not np.array_equal(kit["ref_pair_w21_callsite/s2_lr"], kit["ref_pair_w21_callsite/s1_uniq"])
     assert not np.array_equal(kit["ref_pair_w21_callsite/s3_full"], kit["ref_pair_w21_callsite/s2_lr"])
+
+
+def test_verifier_runs_end_to_end_with_a_stand_in(kit, oracle, monkeypatch, capsys):
+    """tools/verify_with_opencv.py against a stand-in `cv2` whose StereoBM is the oracle: the script's own logic (parameter
+    transport through the cv2 setter names, staging, first-difference report, exit code) runs here; it says nothing about the
+    real OpenCV, and a deliberately broken stand-in must be caught at the right stage."""
+    import sys
+    import types
+
+    class FakeBM:
+        def __init__(self, numDisparities, blockSize, break_lr=False):
+            self.p = dict(num_disparities=numDisparities, block_size=blockSize, prefilter_type=1, prefilter_size=9, prefilter_cap=31,
+                          min_disparity=0, texture_threshold=10, uniqueness_ratio=15, speckle_window_size=0, speckle_range=0,
+                          disp12_max_diff=-1, roi1=(0, 0, 0, 0), roi2=(0, 0, 0, 0))
+            self.break_lr = break_lr
+
+        def setPreFilterType(self, v): self.p["prefilter_type"] = v
+        def setPreFilterSize(self, v): self.p["prefilter_size"] = v
+        def setPreFilterCap(self, v): self.p["prefilter_cap"] = v
+        def setMinDisparity(self, v): self.p["min_disparity"] = v
+        def setTextureThreshold(self, v): self.p["texture_threshold"] = v
+        def setUniquenessRatio(self, v): self.p["uniqueness_ratio"] = v
+        def setSpeckleWindowSize(self, v): self.p["speckle_window_size"] = v
+        def setSpeckleRange(self, v): self.p["speckle_range"] = v
+        def setDisp12MaxDiff(self, v): self.p["disp12_max_diff"] = v if not self.break_lr else -1
+        def setROI1(self, r): self.p["roi1"] = tuple(r)
+        def setROI2(self, r): self.p["roi2"] = tuple(r)
+
+        def compute(self, L, R):
+            q = self.p
+            po = oracle.make_params(q["num_disparities"], q["block_size"], q["prefilter_cap"], q["min_disparity"], q["texture_threshold"],
+                                    q["uniqueness_ratio"], q["speckle_window_size"], q["speckle_range"], q["disp12_max_diff"],
+                                    q["prefilter_type"], q["prefilter_size"], q["roi1"], q["roi2"])
+            return oracle.compute(po, L, R)
+
+    ver = _load(ROOT / "tools" / "verify_with_opencv.py", "pin_kit_ver2")
+    for broken in (False, True):
+        fake = types.ModuleType("cv2")
+        fake.__version__ = "stand-in"
+        fake.StereoBM_create = lambda numDisparities=0, blockSize=21, _b=broken: FakeBM(numDisparities, blockSize, _b)
+        monkeypatch.setitem(sys.modules, "cv2", fake)
+        monkeypatch.setattr(sys, "argv", ["verify_with_opencv.py", str(KIT)])
+        rc = ver.main()
+        out = capsys.readouterr().out
+        if not broken:
+            assert rc == 0 and "ALL CASES AGREE" in out
+        else:
+            assert rc == 1 and "FIRST DIFFERENCE at stage s2_lr" in out and "stage s0_wta" not in out and "stage s1_uniq" not in out
