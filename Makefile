@@ -4,7 +4,7 @@ PKG := u96-slam_amd
 CSRC := $(PKG)/csrc
 LIB := $(PKG)/lib/libsbm_hip.so
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
-SRCS := $(CSRC)/sbm_api.hip $(CSRC)/sbm_prefilter.hip $(CSRC)/sbm_sad_generic.hip $(CSRC)/sbm_sad_fast.hip $(CSRC)/sbm_sad_fast_pw1.hip $(CSRC)/sbm_sad_fast_pw2.hip $(CSRC)/sbm_sad_fast_pp.hip $(CSRC)/sbm_post.hip $(CSRC)/sbm_consume.hip $(CSRC)/sbm_rectify.hip $(CSRC)/sbm_fpga.hip $(CSRC)/sbm_gftt.hip
+SRCS := $(CSRC)/sbm_api.hip $(CSRC)/sbm_prefilter.hip $(CSRC)/sbm_sad_generic.hip $(CSRC)/sbm_sad_wide.hip $(CSRC)/sbm_sad_fast.hip $(CSRC)/sbm_sad_fast_pw1.hip $(CSRC)/sbm_sad_fast_pw2.hip $(CSRC)/sbm_sad_fast_pp.hip $(CSRC)/sbm_post.hip $(CSRC)/sbm_consume.hip $(CSRC)/sbm_rectify.hip $(CSRC)/sbm_fpga.hip $(CSRC)/sbm_gftt.hip
 OBJS := $(SRCS:.hip=.o)
 
 all: $(LIB) oracle

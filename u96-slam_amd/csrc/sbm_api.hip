@@ -544,6 +544,9 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
       int xa = 0, xb = 0;
       HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, border, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", g_sad_kernel_name);
+    } else if (sad_wide_supported(g) && env_switch("SBM_WIDE", 1)) {
+      HIPCHK(h, launch_sad_wide(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
+      snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_wide_kernel");
     } else {
       HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_generic_kernel");

@@ -12,7 +12,7 @@ namespace sbm {
 // Environment switches of the library -- the complete list, documented for integrators in include/sbm.h ("Environment").
 //   env_switch(): read in every build. They select a tested fallback or a code path that the GPU tests compare with the
 //                 default one: SBM_FAST_INPLACE, SBM_FAST_MODE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS,
-//                 SBM_SPECKLE_BAND, SBM_HOST_ZEROCOPY.
+//                 SBM_SPECKLE_BAND, SBM_HOST_ZEROCOPY, SBM_WIDE.
 //   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_NSEG, SBM_FAST_TAPER,
 //                 SBM_FAST_UNIQ_PLAIN, SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*): compiled in
 //                 only with -DSBM_DEV (the development library of tools/exp/r04_devlib.sh); the product ignores them.
@@ -65,6 +65,12 @@ hipError_t launch_prefilter_norm(const uint8_t* d_left, const uint8_t* d_right, 
 // any disparity count, clamped border windows. Used for the border columns and as the fallback path.
 hipError_t launch_sad_generic(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g,
                               int xa, int xb, hipStream_t s);
+
+// The same definition and outputs with sliding sums in both directions (sbm_sad_wide.hip): the fallback outside the fast
+// envelope for up to 2048 disparities; SBM_WIDE=0 selects the per-column kernel above instead.
+bool sad_wide_supported(const Geom& g);
+hipError_t launch_sad_wide(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g, int xa, int xb,
+                           hipStream_t s);
 
 // Fast path (interior columns, block size multiple of 3 up to 21, 16-bit sums). Returns hipErrorNotSupported
 // when the configuration is outside its envelope; *xa,*xb receive the column range it covered.
