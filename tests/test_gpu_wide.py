@@ -1,4 +1,4 @@
-"""The fallback outside the fast kernel's envelope (sbm_sad_wide.hip: block sizes above 27, more than 256 disparities, sums
+"""The fallback outside the fast kernel's envelope (sbm_sad_wide.hip: block sizes above 27, more than 512 disparities, sums
 beyond 16 bits) against the oracle, stage by stage, and against the per-column kernel it replaced (SBM_WIDE=0; the switch is
 read at every call). Bit-exact: integer path, tolerance 0."""
 import pathlib
@@ -26,8 +26,9 @@ CASES = [
     (260, 90, 2, dict(num_disparities=64, block_size=29)),                                    # one chunk, one wavefront
     (400, 100, 1, dict(num_disparities=128, block_size=31, uniqueness_ratio=15)),             # two wavefronts
     (360, 120, 3, dict(num_disparities=96, block_size=45, texture_threshold=40)),             # masked lanes, big window
-    (420, 70, 2, dict(num_disparities=272, block_size=15, uniqueness_ratio=10)),              # 5 chunks on 5 wavefronts
-    (700, 60, 1, dict(num_disparities=512, block_size=21, uniqueness_ratio=10)),              # 8 wavefronts
+    (700, 70, 2, dict(num_disparities=528, block_size=15, uniqueness_ratio=10)),              # 9 chunks on 8 wavefronts
+    (420, 60, 1, dict(num_disparities=272, block_size=29, uniqueness_ratio=10)),              # 5 chunks on 5 wavefronts
+    (700, 60, 1, dict(num_disparities=512, block_size=31, uniqueness_ratio=10)),              # 8 wavefronts
     (1150, 40, 1, dict(num_disparities=1040, block_size=9, uniqueness_ratio=5)),              # 17 chunks: 3 per wavefront (<4>)
     (900, 36, 1, dict(num_disparities=768, block_size=11, uniqueness_ratio=0)),               # 12 chunks: 2 per wavefront (<2>)
     (2200, 30, 1, dict(num_disparities=2048, block_size=7, uniqueness_ratio=10)),             # the kernel's maximum
@@ -63,9 +64,9 @@ def test_wide_kernel_against_oracle_and_per_column_kernel(torch_cuda, pkg, oracl
 def test_wide_kernel_is_the_one_that_runs(torch_cuda, pkg, monkeypatch):
     from u96_slam_amd import synth
 
-    L, R = synth.make_batch(1, 1, 500, 80, 64)
-    for wide, nd, wsz, want in (("1", 64, 29, "sad_wide_kernel"), ("0", 64, 29, "sad_generic_kernel"), ("1", 320, 15, "sad_wide_kernel"),
-                                ("1", 64, 21, "sad_fast_kernel")):
+    L, R = synth.make_batch(1, 1, 800, 80, 64)
+    for wide, nd, wsz, want in (("1", 64, 29, "sad_wide_kernel"), ("0", 64, 29, "sad_generic_kernel"), ("1", 528, 15, "sad_wide_kernel"),
+                                ("1", 320, 15, "sad_fast_kernel<128,3,"), ("1", 64, 21, "sad_fast_kernel<")):
         monkeypatch.setenv("SBM_WIDE", wide)
         bm = pkg.StereoBM.create(nd, wsz)
         bm.compute(L, R)
@@ -89,3 +90,56 @@ def test_wide_kernel_frame_sized_properties(torch_cuda, pkg, monkeypatch):
     b = bm.compute(L, R)
     assert np.array_equal(a[:2], b)
     assert (a >= 0).mean() > 0.2
+
+
+# ---- 257 .. 512 disparities inside the interior kernel: three / four cooperating 128-disparity wavefronts, their clamped border
+# ---- columns from the sliding-sum kernel (16-bit cost plane, pre-scaled planes)
+ND512 = [
+    (700, 64, 2, dict(num_disparities=272, block_size=15, uniqueness_ratio=10)),       # <128,3>, 16 disparities in the last wavefront
+    (760, 70, 1, dict(num_disparities=384, block_size=21, uniqueness_ratio=15)),       # <128,3> full
+    (800, 60, 3, dict(num_disparities=400, block_size=9, uniqueness_ratio=10)),        # <128,4>, 16 in the last wavefront
+    (900, 66, 1, dict(num_disparities=512, block_size=27, uniqueness_ratio=10)),       # <128,4> full, 9-term window
+    (820, 58, 2, dict(num_disparities=448, block_size=11, uniqueness_ratio=5)),        # 1-column sums
+    (860, 72, 1, dict(num_disparities=320, block_size=19, uniqueness_ratio=0, texture_threshold=0)),
+    (840, 64, 1, dict(num_disparities=496, block_size=5, min_disparity=-9, uniqueness_ratio=10)),
+    (880, 90, 1, dict(num_disparities=336, block_size=25, min_disparity=13, uniqueness_ratio=10)),
+    (1000, 50, 9, dict(num_disparities=512, block_size=15, uniqueness_ratio=10)),      # more pairs than XCDs
+]
+
+
+@pytest.mark.parametrize("lr", [-1, 1])
+@pytest.mark.parametrize("case", range(len(ND512)))
+def test_interior_kernel_up_to_512_disparities(torch_cuda, pkg, oracle, case, lr):
+    from test_gpu_parity import assert_stages_equal, run_engine
+    from u96_slam_amd import synth
+
+    w, h, n, kw = ND512[case]
+    kw = dict(dict(prefilter_cap=31, texture_threshold=10, speckle_window_size=20, speckle_range=8), **kw)
+    kw["disp12_max_diff"] = lr
+    L, R = synth.make_batch(70 + case, n, w, h, min(kw["num_disparities"], w // 3))
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+    assert np.array_equal(eng["disp"], ref["disp"])
+    bm = pkg.StereoBM.create(kw["num_disparities"], kw["block_size"])
+    bm.compute(L[:1], R[:1])
+    nw = 3 if kw["num_disparities"] <= 384 else 4
+    assert bm.last_kernel().startswith(f"sad_fast_kernel<128,{nw},"), bm.last_kernel()
+
+
+def test_interior_kernel_512_frame_sized(torch_cuda, pkg, oracle):
+    """One 2160p-wide band at 512 disparities, 21x21, every post-filter: whole map against the oracle (a few seconds of CPU)."""
+    from u96_slam_amd import synth
+
+    L, R = synth.make_batch(5, 1, 3840, 160, 400)
+    kw = dict(num_disparities=512, block_size=21, prefilter_cap=31, texture_threshold=10, uniqueness_ratio=10,
+              speckle_window_size=50, speckle_range=32, disp12_max_diff=1)
+    bm = pkg.StereoBM.create(512, 21)
+    for k, f in (("uniqueness_ratio", bm.setUniquenessRatio), ("disp12_max_diff", bm.setDisp12MaxDiff),
+                 ("speckle_window_size", bm.setSpeckleWindowSize), ("speckle_range", bm.setSpeckleRange),
+                 ("texture_threshold", bm.setTextureThreshold)):
+        f(kw[k])
+    got = bm.compute(L, R)
+    p = oracle.make_params(**kw)
+    ref = oracle.compute(p, L[0], R[0])
+    assert np.array_equal(got[0], ref)
+    assert bm.last_kernel().startswith("sad_fast_kernel<128,4,7,3,false")

@@ -544,6 +544,10 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
       int xa = 0, xb = 0;
       HIPCHK(h, launch_sad_fast(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, &xa, &xb, border, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "%s", g_sad_kernel_name);
+      if (border && !sad_fast_borders_in_launch(g)) {   // beyond 256 disparities: the clamped columns from the sliding-sum kernel
+        HIPCHK(h, launch_sad_wide(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, xa, h->stream));
+        HIPCHK(h, launch_sad_wide(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, xb, g.xend, h->stream));
+      }
     } else if (sad_wide_supported(g) && env_switch("SBM_WIDE", 1)) {
       HIPCHK(h, launch_sad_wide(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_wide_kernel");

@@ -78,6 +78,8 @@ hipError_t launch_sad_wide(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
 extern thread_local char g_sad_kernel_name[96];
 bool sad_fast_supported(const Geom& g);
 bool mqsad_inplace_ok(hipStream_t s);   // device self-test behind the in-place v_mqsad accumulate (cached per device)
+constexpr int kFastNdMax = 512;   // disparities the interior kernel takes (four cooperating 128-disparity wavefronts)
+bool sad_fast_borders_in_launch(const Geom& g);   // the clamped border columns ride in the interior launch (up to 256 disparities)
 int sad_fast_pfshift(const Geom& g);   // 2 or 1 when the interior kernel wants pre-scaled planes (see kPfBias), else 0
 // border: the w/2 clamped columns on each side of [xa,xb) are computed by extra wavefronts of the same launch
 // (sbm_sad_border_wave.h); without it the launch leaves them untouched.

@@ -1086,6 +1086,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
   {
     // The grid starts with the border jobs (a.bord workgroups for each of their a.nbseg row segments, sbm_sad_border_wave.h):
     // they are long serial chains, so they are dispatched before any strip and finish under the strips instead of behind them.
+    if constexpr (NDW * NWAVES <= 256) {   // (a border wavefront holds a disparity quad per lane: up to 256; launch_t never asks beyond)
     if ((int)blockIdx.x < a.bord * a.nbseg) {
       // wavefront wv of border workgroup b takes border wavefront b * NWAVES + wv of its segment; no barriers in there
       using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
@@ -1094,6 +1095,7 @@ __global__ void __launch_bounds__(64 * NWAVES) SBM_FAST_WAVES_PER_EU sad_fast_ke
       const int wi = b * NWAVES + wv;
       if (wi < a.bnw) sad_border_wave<(PW * NTERM) / 2, NDW * NWAVES>(a, reinterpret_cast<unsigned char*>(fast_lds) + wv * BL::BYTES, bseg, wi);
       return;
+    }
     }
     const int sid = blockIdx.x - a.bord * a.nbseg;
     const int per_seg = a.strips * a.npairs;
@@ -1231,9 +1233,14 @@ int sad_fast_pfshift(const Geom& g) {
   return 0;
 }
 
+bool sad_fast_borders_in_launch(const Geom& g) { return g.nd <= 256; }
+
 bool sad_fast_supported(const Geom& g) {
   if (g.wsz < 5 || g.wsz > 27) return false;   // every odd window 5..27: multiples of 3 with 3-column sums, the rest 1-column
-  if (g.nd > 256) return false;
+  if (g.nd > kFastNdMax) return false;
+  // beyond 256 disparities: three / four cooperating 128-disparity wavefronts (not in the two-accumulator fallback build);
+  // their border columns come from the sliding-sum kernel (sbm_sad_wide.hip) in launches of their own
+  if (g.nd > 256 && !mqsad_inplace_ok(nullptr)) return false;
   const long maxs = (long)g.wsz * g.wsz * 2 * g.cap;
   if (maxs > 65534) return false;
   if (2 * (maxs * g.uniq / 100 + 1) >= 65535) return false;
@@ -1264,7 +1271,9 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
     lds = (size_t)NWAVES * (WB1 > WB3 ? WB1 : WB3) + (NWAVES > 1 ? (size_t)2 * NWAVES * 64 * (4 + 8) : 0);
   }
   a.bord = a.bnw = 0;
-  if (border) {
+  a.bseg = a.row1 - a.row0;
+  a.nbseg = 0;
+  if constexpr (NDW * NWAVES <= 256) if (border) {
     // border wavefronts per segment: 2 sides x ceil(n / JW) groups of JW consecutive pairs, NWAVES of them per workgroup
     using BL = BorderLds<(PW * NTERM) / 2, NDW * NWAVES>;
     a.bnw = 2 * ((a.npairs + BL::JW - 1) / BL::JW);
@@ -1284,9 +1293,6 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
     a.nbseg = (rows + bseg - 1) / bseg;
     a.bseg = (rows + a.nbseg - 1) / a.nbseg;
     a.nbseg = (rows + a.bseg - 1) / a.bseg;
-  } else {
-    a.bseg = a.row1 - a.row0;
-    a.nbseg = 0;
   }
   dim3 grid((unsigned)(a.bord * a.nbseg + a.strips * a.npairs * a.nseg));
   if (SBM_TUNE("SBM_DEV_PRINT", 0))   // development builds: the launch geometry
@@ -1296,7 +1302,8 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   if (SBM_TUNE("SBM_DEV_BORDER_ONLY", 0)) grid.x = (unsigned)(a.bord * a.nbseg);
   // (the fallback build only carries the masked-count kernels: they are right for every count up to NDW * NWAVES)
   // ... and <64,4> only runs one-pair calls beyond 192 disparities: its masked kernel serves 256 as well
-  constexpr bool HAS_EXACT = !SBM_FAST_PINGPONG && !(NDW == 64 && NWAVES == 4);
+  // ... and so do the three and four 128-disparity wavefronts (257 .. 512 disparities)
+  constexpr bool HAS_EXACT = !SBM_FAST_PINGPONG && !(NDW == 64 && NWAVES == 4) && !(NDW == 128 && NWAVES >= 3);
   const bool exact = HAS_EXACT && a.nd == NDW * NWAVES;
   snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
            NDW, NWAVES, NTERM, PW, exact ? "true" : "false", DUAL ? "true" : "false", a.pfshift);
@@ -1322,6 +1329,8 @@ static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split
   if (a.nd <= 192) return launch_t<64, 3, NTERM, PW>(a, border, s);
   return launch_t<64, 4, NTERM, PW>(a, border, s);
 #else
+  if (a.nd > 384) return launch_t<128, 4, NTERM, PW>(a, border, s);   // (whatever SBM_FAST_MODE says: the only layouts up there)
+  if (a.nd > 256) return launch_t<128, 3, NTERM, PW>(a, border, s);
   if (a.nd <= 32) return launch_t<32, 1, NTERM, PW>(a, border, s);
   if (a.nd == 48 && SBM_TUNE("SBM_DEV_ND48", 0)) return launch_t<32, 2, NTERM, PW>(a, border, s);   // (rounds 1-3: two 32-disparity wavefronts)
   // one-pair calls: too few workgroups to fill the chip, so split the disparities over two wavefronts (half the serial work
@@ -1423,10 +1432,12 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   // 10-14, formula 12, round 4's rule 6: 0.476 -> 0.469 ms; 1080p nd 256 x64 best 6-8, formula 6.6, round 4's 4: 8.28 -> 8.19;
   // 2160p x32 best 8-12, formula 9, round 4's 3: 17.64 -> 16.97; 1080p x16 and 2160p x4 unchanged at 13 and 25). Round 4's rule
   // (a workgroup target of 24 000 / 5 600 with segments of at least three window heights) was tuned at 64 / 16 / 4 pairs only.
+  // (one round of the chip for the cooperating 128-disparity wavefronts: 12 wavefronts per CU in workgroups of 2 / 3 / 4)
+  const int round1 = g.nd <= 256 ? 1536 : (g.nd <= 384 ? 1024 : 768);
   int nseg = 1;
   {
     const double prime = 0.2 * (g.wsz - 1);
-    const double slots = g.nd <= 64 ? 4096.0 : (g.nd <= 128 ? 3072.0 : 1536.0);
+    const double slots = g.nd <= 64 ? 4096.0 : (g.nd <= 128 ? 3072.0 : (double)round1);
     static const int c1000 = SBM_TUNE("SBM_DEV_SEG_C", 196);
     nseg = (int)(std::sqrt(c1000 * 1e-3 * slots * rows / ((double)strips * g.n * prime)) + 0.5);
     nseg = std::max(1, std::min(nseg, std::max(1, rows / g.wsz)));   // (at least one window height per segment here; see below)
@@ -1441,14 +1452,14 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   static const long fill = SBM_TUNE("SBM_DEV_FILL", 5000);
   const int maxseg = std::max(nseg, std::min(64, rows / small_rows));
   const long per_seg = (long)strips * g.n;
-  if (per_seg * maxseg * (g.nd > 128 ? 2 : 1) < 1800) {
+  if (per_seg * maxseg * (g.nd > 128 ? (g.nd + 127) / 128 : 1) < 1800) {
     nseg = std::max(nseg, (int)std::min<long>(maxseg, 1023 / per_seg));
   } else {
     const int nseg1 = nseg;
     while (per_seg * nseg < fill && nseg < maxseg) nseg++;
     // (two cooperating 128-disparity wavefronts: 1 536 workgroups are one round of the chip; a launch that ends between 1 and
     // 1.5 rounds pays a second, mostly empty round -- one 1080p nd 256 pair: 64 segments 0.204 ms, 36..48 segments 0.189..0.196)
-    if (g.nd > 128 && per_seg * nseg > 1536 && per_seg * nseg < 2304) nseg = std::max(nseg1, (int)(1450 / per_seg));
+    if (g.nd > 128 && per_seg * nseg > round1 && 2 * per_seg * nseg < 3 * round1) nseg = std::max(nseg1, (int)((long)round1 * 1450 / 1536 / per_seg));
   }
   static const int nseg_env = SBM_TUNE("SBM_FAST_NSEG", 0);
   if (nseg_env > 0) nseg = std::min(nseg_env, std::max(1, rows / 2));

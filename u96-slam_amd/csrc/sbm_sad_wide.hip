@@ -35,6 +35,7 @@ struct WideArgs {
   int nd, mindisp, wsz, cap, lofs, rofs, tex, uniq, filtered;
   int row0, row1, xa, xb;
   int tx, seg;
+  int pfshift, cost16;   // planes hold (value << pfshift) + 1; the cost plane holds uint16 (0xffff = filtered) -- border columns of the fast path
 };
 
 __device__ __forceinline__ int wclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(64 * kWideWaves) sad_wide_kernel(WideArgs a) {
   const int ys = a.row0 + (int)blockIdx.y * a.seg, ye = min(ys + a.seg, a.row1);
   const int pair = (int)blockIdx.z;
   const int w2 = a.wsz / 2, nd = a.nd, nch = (nd + 63) >> 6, nds = nch * 64;
-  const u32 capw = (u32)(a.cap + kPfBias);
+  const u32 capw = (u32)((a.cap << a.pfshift) + kPfBias);
   // row bases (column 0 of the padded planes); a left byte sits at lofs + clamped column, a right byte at rofs + clamped column + d
   const uint8_t* const pl = a.pf_l + (size_t)pair * a.plane + a.padl;
   const uint8_t* const pr = a.pf_r + (size_t)pair * a.plane + a.padl;
@@ -204,7 +205,9 @@ __global__ void __launch_bounds__(64 * kWideWaves) sad_wide_kernel(WideArgs a) {
         best = k < best ? k : best;
       }
       const int minsad = (int)(best >> 32), mind = (int)(best & 0xffffffffu);
-      fin[xi] = make_int4(minsad, mind, minsad + (minsad * a.uniq / 100), T[xi] >= a.tex ? 1 : 0);
+      // (pre-scaled planes: every sum is a multiple of 1 << pfshift; the threshold is defined on the unscaled sum)
+      const int ms = minsad >> a.pfshift;
+      fin[xi] = make_int4(minsad, mind, (ms + (ms * a.uniq / 100)) << a.pfshift, (T[xi] >> a.pfshift) >= a.tex ? 1 : 0);
       uq[xi] = 0u;
     }
     __syncthreads();
@@ -237,7 +240,10 @@ __global__ void __launch_bounds__(64 * kWideWaves) sad_wide_kernel(WideArgs a) {
       }
       const size_t o = obase + (size_t)y * a.W + a.lofs + x0 + xi;
       a.disp[o] = (int16_t)out;
-      if (a.cost && ok) a.cost[o] = f.x;
+      if (a.cost) {
+        if (a.cost16) reinterpret_cast<uint16_t*>(a.cost)[o] = ok ? (uint16_t)(f.x >> a.pfshift) : (uint16_t)0xffffu;
+        else if (ok) a.cost[o] = f.x;
+      }
     }
     __syncthreads();   // S, pm, fin are rewritten by the next row
   }
@@ -255,6 +261,7 @@ hipError_t launch_sad_wide(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   a.nd = g.nd; a.mindisp = g.mindisp; a.wsz = g.wsz; a.cap = g.cap; a.lofs = g.lofs; a.rofs = g.rofs;
   a.tex = g.tex; a.uniq = g.uniq; a.filtered = g.filtered;
   a.row0 = g.row0; a.row1 = g.row1; a.xa = xa; a.xb = xb;
+  a.pfshift = g.pfshift; a.cost16 = g.cost16;
   const int nch = (g.nd + 63) / 64, nw = std::min(kWideWaves, nch), cpw = (nch + nw - 1) / nw;
   const int rows = g.row1 - g.row0, cols = xb - xa;
   // tile: S of a workgroup sized for ~16 wavefronts per CU (160 KB of LDS: 10 KB per wavefront of the workgroup), at most 64
