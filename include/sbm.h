@@ -23,18 +23,19 @@
  * SBM_ERR_NO_DEVICE. The CPU restatement used by the tests lives in oracle/ and is never linked here.
  *
  * Exactness. Every parameter set cv::StereoBM accepts is computed (block sizes 5..255, any multiple of 16 disparities, any
- * minDisparity / ROI); sets inside the fast envelope -- odd block size 5..27, numDisparities <= 256, blockSize^2 * 2 *
- * preFilterCap <= 65534 -- run the hand-tuned kernels, everything else a generic kernel (~50x slower, same results).
+ * minDisparity / ROI); sets inside the fast envelope -- odd block size 5..27, numDisparities <= 512, blockSize^2 * 2 *
+ * preFilterCap <= 65534 -- run the hand-tuned kernels (4 T pixel-disparities/s), everything else a sliding-sum kernel with 32-bit
+ * sums (0.15-0.5 T, same results; up to 2048 disparities, beyond that a per-column kernel ~10x slower again).
  * Bit-exactness against cv::StereoBM is CLAIMED for blockSize^2 * 2 * preFilterCap <= 32767 only (the reference's 21 x 21
  * at cap 31 is 27 342): OpenCV keeps its block-matching cost plane as `short`, so beyond that bound its left-right check
  * would see a wrapped cost where this engine (and its oracle) keep the true one.
  *
- * Environment. The library reads these seven variables (nothing else); an integrator never needs to set any of them:
+ * Environment. The library reads these eight variables (nothing else); an integrator never needs to set any of them:
  *   variable            default  read      who sets it, and what for
  *   SBM_FAST_INPLACE    1        once      0 = run the two-accumulator build of the SAD kernel (the fallback that is taken
  *                                          automatically when the device self-test of the in-place v_mqsad accumulate
  *                                          fails); set by the GPU tests to check that fallback
- *   SBM_FAST_MODE       2        once      layout of the interior SAD kernel beyond 64 disparities: 2 = one 128-disparity
+ *   SBM_FAST_MODE       2        once      layout of the interior SAD kernel from 65 to 256 disparities: 2 = one 128-disparity
  *                                          wavefront up to 128, two of them beyond (three 64-disparity ones at exactly 192);
  *                                          1 = one 128-disparity wavefront up to 128, 64-disparity cooperating wavefronts
  *                                          beyond; 0 = 64 disparities per wavefront everywhere (round-2 layout); GPU tests /
@@ -49,6 +50,8 @@
  *                                          pageable memory return their maps through a D2H copy + stream synchronisation instead of
  *                                          the copy kernel that writes pinned host memory and raises a flag the host polls; GPU
  *                                          tests / A-B measurements
+ *   SBM_WIDE            1        per call  0 = configurations outside the fast envelope run the per-column kernel
+ *                                          (sbm_sad_generic.hip) instead of the sliding-sum one (sbm_sad_wide.hip); GPU tests
  * Tuning knobs of the measurement scripts (SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
  * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*) exist only in development builds (-DSBM_DEV,
  * tools/exp/r04_devlib.sh); this library ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this
@@ -198,15 +201,16 @@ int sbm_debug_fetch(sbm_handle* h, int which, void* dst, size_t dst_bytes);
  *              (which synchronises) returns the average over the calls made since enabling (last 64 at most).
  * enabled = 3: as 2, but only every 4th call is instrumented (the five event records cost ~20 us per call at the bench size;
  *              sampling keeps a timed region close to the un-instrumented rate).
- * names: "prefilter", "sad" (the SAD/WTA kernel of the call: the interior kernel, or the generic kernel when the fast path is
- * off -- sbm_last_kernel_name() says which), "lrcheck", "speckle", "total"; "border" is still accepted and reads 0 (the
- * clamped border columns have been wavefronts of the SAD launch since round 4: there is no second kernel to time). */
+ * names: "prefilter", "sad" (the SAD/WTA kernels of the call: the interior kernel -- plus, beyond 256 disparities, the two
+ * launches for its clamped border columns -- or the sliding-sum / per-column kernel when the fast path is off;
+ * sbm_last_kernel_name() says which), "lrcheck", "speckle", "total"; "border" is still accepted and reads 0 (up to 256
+ * disparities the clamped border columns have been wavefronts of the SAD launch since round 4: no second kernel to time). */
 int sbm_set_profiling(sbm_handle* h, int enabled);
 int sbm_get_profile(sbm_handle* h, const char* name, float* ms);
 
 /* Which SAD kernel the LAST sbm_compute_device call launched, as text: the template instantiation of the interior
  * kernel ("sad_fast_kernel<128,1,5,3,true> pfshift=2"; "sad_fast_pp_kernel<...>" = its two-accumulator fallback build)
- * or "sad_generic_kernel" when the configuration is outside the fast envelope. bench.py compares it with the kernel the
+ * or "sad_wide_kernel" / "sad_generic_kernel" when the configuration is outside the fast envelope. bench.py compares it with the kernel the
  * committed counter profile was taken on, so that stale counters are never attached to a different kernel. */
 int sbm_last_kernel_name(sbm_handle* h, char* dst, size_t dst_bytes);
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak test on the GPU: many seeded random configurations (sizes, windows 5..29, disparity counts, every post-filter
-combination, batches) against the oracle, stage by stage; every configuration is also run twice for determinism.
+combination, batches; since round 5 windows up to 41 and up to 528 disparities: the 3 / 4-wavefront layouts and the sliding-sum
+fallback kernel) against the oracle, stage by stage; every configuration is also run twice for determinism.
 usage: python tools/soak.py [--iters 400] [--seed 1]   -> prints a JSON summary, exit code 1 on any mismatch"""
 import argparse
 import json
@@ -44,8 +45,8 @@ def main():
     bad = []
     t0 = time.time()
     for it in range(args.iters):
-        wsz = int(rng.choice([5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29]))
-        nd = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 192, 208, 256, 272]))
+        wsz = int(rng.choice([5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 41]))
+        nd = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 192, 208, 256, 272, 320, 384, 400, 512, 528]))
         mind = int(rng.choice([0, 0, 0, -16, 5, -nd // 2, 17]))
         n = int(rng.choice([1, 1, 2, 3, 5]))
         h = int(rng.integers(wsz + 8, wsz + 90))
