@@ -142,4 +142,4 @@ def test_interior_kernel_512_frame_sized(torch_cuda, pkg, oracle):
     p = oracle.make_params(**kw)
     ref = oracle.compute(p, L[0], R[0])
     assert np.array_equal(got[0], ref)
-    assert bm.last_kernel().startswith("sad_fast_kernel<128,4,7,3,false")
+    assert bm.last_kernel().startswith("sad_fast_kernel<128,4,7,3,true")

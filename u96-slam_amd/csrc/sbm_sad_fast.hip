@@ -47,6 +47,9 @@
 
 #include "sbm_common.h"
 
+#ifndef SBM_FAST_EXACT512   // exact-count kernels for 384 and 512 disparities (three / four full 128-disparity wavefronts)
+#define SBM_FAST_EXACT512 1
+#endif
 #ifndef SBM_FAST_PRIO_XCH   // s_setprio level during the horizontal exchange (0 = off; development builds compare)
 #define SBM_FAST_PRIO_XCH 2
 #endif
@@ -1302,8 +1305,9 @@ static hipError_t launch_t(FastArgs a, bool border, hipStream_t s) {
   if (SBM_TUNE("SBM_DEV_BORDER_ONLY", 0)) grid.x = (unsigned)(a.bord * a.nbseg);
   // (the fallback build only carries the masked-count kernels: they are right for every count up to NDW * NWAVES)
   // ... and <64,4> only runs one-pair calls beyond 192 disparities: its masked kernel serves 256 as well
-  // ... and so do the three and four 128-disparity wavefronts (257 .. 512 disparities)
-  constexpr bool HAS_EXACT = !SBM_FAST_PINGPONG && !(NDW == 64 && NWAVES == 4) && !(NDW == 128 && NWAVES >= 3);
+  // (three and four 128-disparity wavefronts, 257 .. 512 disparities: exact kernels for 384 and 512 -- 5-7 % over the masked ones,
+  // profiles/r05_exact512.txt; SBM_FAST_EXACT512=0 drops them: 24 kernels, 0.6 MB, ~15 s of build)
+  constexpr bool HAS_EXACT = !SBM_FAST_PINGPONG && !(NDW == 64 && NWAVES == 4) && !(NDW == 128 && NWAVES >= 3 && !SBM_FAST_EXACT512);
   const bool exact = HAS_EXACT && a.nd == NDW * NWAVES;
   snprintf(g_sad_kernel_name, sizeof(g_sad_kernel_name), "%s<%d,%d,%d,%d,%s,%s> pfshift=%d", SBM_FAST_PINGPONG ? "sad_fast_pp_kernel" : "sad_fast_kernel",
            NDW, NWAVES, NTERM, PW, exact ? "true" : "false", DUAL ? "true" : "false", a.pfshift);
