@@ -509,7 +509,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel ---------------------------------------------------------------------
-        kms = prof["sad"]   # the SAD/WTA kernel of the call (interior kernel, or the generic one: `kernel` says which)
+        kms = prof["sad"]   # the SAD/WTA kernel of the call (interior kernel -- beyond 256 disparities with its two border launches -- or a fallback one: `kernel` says which)
         algo_bytes = 4.0 * W * H * B  # read L+R (2 B/px) + write int16 disparity (2 B/px) per pair
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         traffic = None
