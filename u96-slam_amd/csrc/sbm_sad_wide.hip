@@ -1,5 +1,6 @@
 // sbm_sad_wide.hip -- SAD / WTA / texture / uniqueness / sub-pixel for configurations outside the fast kernel's envelope
-// (block sizes above 27, more than 256 disparities, sums beyond 16 bits), gfx950.
+// (block sizes above 27, more than 512 disparities, sums beyond 16 bits) and for the clamped border columns of the fast kernel
+// beyond 256 disparities, gfx950.
 //
 // Same definition as sbm_sad_generic.hip (findStereoCorrespondenceBM of OpenCV calib3d stereobm.cpp as reached from
 // src/slam/src/core/main.cpp:215; clamped windows, 32-bit sums, first minimum wins -- SURVEY.md Appendix A.3/A.4), evaluated
@@ -9,11 +10,13 @@
 //   lanes = disparities.  S[x][d] (window sums of the current row, 32 bit) lives in LDS.
 //   per row:  A  every wavefront walks the tile left to right with D(d) = H_enter(x, d) - H_leave(x, d) in a register per
 //                chunk (H = horizontal window sum of one row; one step = two bytes in, two bytes out per row), adds it to
-//                S[x][d] and reduces its chunks to a partial winner (DPP minimum, ballot for the first index);
-//             B  a thread per column merges the partial winners, slides the texture sum, derives the uniqueness threshold;
+//                S[x][d] and reduces its chunks to a partial winner (one DPP minimum over keys sum << 6 | lane); wavefront 0
+//                slides the texture sums along (the left bytes are wavefront-uniform);
+//             B  a thread per column merges the partial winners and derives the uniqueness threshold;
 //             C  every wavefront tests its chunks against the threshold (ballot);
 //             D  a thread per column: neighbours from S, sub-pixel fit, stores.
-//   Cost per (pixel, disparity): ~0.7 wavefront-instructions, independent of the block size (generic kernel: ~4 w).
+//   Cost: ~80-110 wavefront-instructions per (pixel, 64 disparities), independent of the block size (the per-column kernel:
+//   ~4 w per pixel-disparity).
 #include <algorithm>
 #include <type_traits>
 
@@ -40,15 +43,16 @@ struct WideArgs {
 
 __device__ __forceinline__ int wclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// minimum over the wavefront (result wavefront-uniform): butterfly inside each row of 16 lanes by DPP, rows by readlane
+// minimum over the wavefront (result wavefront-uniform): butterfly inside each row of 16 lanes, then lane 15 of a row into the
+// next row, lane 31 into the upper half -- lane 63 ends up with the minimum
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
-  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
-  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, false));   // row_mirror
-  const u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const u32 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  return min(min(a, b), min(c, d));
+  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, false));               // quad_perm [1,0,3,2]
+  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, false));               // quad_perm [2,3,0,1]
+  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, false));              // row_half_mirror
+  v = min(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, false));              // row_mirror
+  v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+  v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 extern __shared__ __attribute__((aligned(16))) u32 wide_lds[];
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(64 * kWideWaves) sad_wide_kernel(WideArgs a) {
 #pragma unroll
       for (int j = 0; j < CPW; j++) {
         ra_in[j] = ra_out[j] = rb_in[j] = rb_out[j] = 0;
-        if (!cv[j]) continue;
+        if (j > 0 && !cv[j]) continue;       // (a wavefront's first chunk always exists)
         ra_in[j] = ra_ip[dld[j]];
         ra_out[j] = ra_op[dld[j]];
         if (!PRIME) { rb_in[j] = rb_ip[dld[j]]; rb_out[j] = rb_op[dld[j]]; }
@@ -143,16 +147,15 @@ __global__ void __launch_bounds__(64 * kWideWaves) sad_wide_kernel(WideArgs a) {
       u32 bS = 0xffffffffu, bD = 0u;       // (wavefront-uniform) winner over this wavefront's chunks
 #pragma unroll
       for (int j = 0; j < CPW; j++) {
-        if (!cv[j]) continue;
+        if (j > 0 && !cv[j]) continue;
         u32* const sp = S + (size_t)xi * nds + dj[j];
         const u32 sn = *sp + D[j];
         *sp = sn;
         if (!PRIME) {
-          const u32 s = dv[j] ? sn : 0xffffffffu;
-          const u32 m = wave_min_u32(s);
-          const u64 hit = __ballot(s == m);
-          const u32 dwin = (u32)(64 * (wave + nw * j)) + (u32)__builtin_ctzll(hit);
-          if (m < bS) { bS = m; bD = dwin; }      // chunks ascend: the first minimum stays
+          // one reduction for the minimum and its first lane: sums stay below 2^26 (255^2 x 126 < 2^23, pre-scaled by at most 4)
+          const u32 key = dv[j] ? (sn << 6) | (u32)lane : 0xffffffffu;
+          const u32 m = wave_min_u32(key);
+          if ((m >> 6) < bS) { bS = m >> 6; bD = (u32)(64 * (wave + nw * j)) + (m & 63u); }   // chunks ascend: the first minimum stays
         }
       }
       if (!PRIME) {
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(64 * kWideWaves) sad_wide_kernel(WideArgs a) {
       // slide the window one column to the right
 #pragma unroll
       for (int j = 0; j < CPW; j++) {
-        if (!cv[j]) continue;
+        if (j > 0 && !cv[j]) continue;
         if (PRIME) {
           D[j] = __builtin_amdgcn_sad_u8(la_in, ra_in[j], D[j]) - __builtin_amdgcn_sad_u8(la_out, ra_out[j], 0u);
         } else {
