@@ -23,7 +23,7 @@
  * SBM_ERR_NO_DEVICE. The CPU restatement used by the tests lives in oracle/ and is never linked here.
  *
  * Exactness. Every parameter set cv::StereoBM accepts is computed (block sizes 5..255, any multiple of 16 disparities, any
- * minDisparity / ROI); sets inside the fast envelope -- odd block size 5..27, numDisparities <= 512, blockSize^2 * 2 *
+ * minDisparity / ROI); sets inside the fast envelope -- odd block size 5..31, numDisparities <= 512, blockSize^2 * 2 *
  * preFilterCap <= 65534 -- run the hand-tuned kernels (4 T pixel-disparities/s), everything else a sliding-sum kernel with 32-bit
  * sums (0.15-0.5 T, same results; up to 2048 disparities, beyond that a per-column kernel ~10x slower again).
  * Bit-exactness against cv::StereoBM is CLAIMED for blockSize^2 * 2 * preFilterCap <= 32767 only (the reference's 21 x 21

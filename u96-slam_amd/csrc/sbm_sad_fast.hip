@@ -61,6 +61,7 @@
 //   SBM_FAST_TU 0  sbm_sad_fast.hip itself: host side + the windows that are multiples of 3 (3-column sums)
 //   SBM_FAST_TU 1  sbm_sad_fast_pw1.hip: the windows 5, 7, 11, 13 (1-column sums), reached through launch_sad_fast_pw1()
 //   SBM_FAST_TU 2  sbm_sad_fast_pw2.hip: the windows 17, 19, 23, 25, reached through launch_sad_fast_pw2()
+//   SBM_FAST_TU 3  sbm_sad_fast_pw3.hip: the windows 29, 31, reached through launch_sad_fast_pw3()
 //   ping-pong      sbm_sad_fast_pp.hip: the two-accumulator fallback, every window, 64-disparity layouts only
 #ifndef SBM_FAST_TU
 #define SBM_FAST_TU 0
@@ -1239,7 +1240,8 @@ int sad_fast_pfshift(const Geom& g) {
 bool sad_fast_borders_in_launch(const Geom& g) { return g.nd <= 256; }
 
 bool sad_fast_supported(const Geom& g) {
-  if (g.wsz < 5 || g.wsz > 27) return false;   // every odd window 5..27: multiples of 3 with 3-column sums, the rest 1-column
+  if (g.wsz < 5 || g.wsz > 31) return false;   // every odd window 5..31: multiples of 3 with 3-column sums, the rest 1-column
+  if (g.wsz > 27 && !mqsad_inplace_ok(nullptr)) return false;   // (29 and 31 are not in the two-accumulator fallback build)   // every odd window 5..27: multiples of 3 with 3-column sums, the rest 1-column
   if (g.nd > kFastNdMax) return false;
   // beyond 256 disparities: three / four cooperating 128-disparity wavefronts (not in the two-accumulator fallback build);
   // their border columns come from the sliding-sum kernel (sbm_sad_wide.hip) in launches of their own
@@ -1354,7 +1356,18 @@ static hipError_t launch_nd(const FastArgs& a, bool border, int mode, bool split
 #endif
 }
 
-// the windows that are not multiples of 3 (1-column sums): 5..13 and 17..25, two translation units in the product build
+// the windows that are not multiples of 3 (1-column sums): 5..13, 17..25 and 29 / 31, three translation units in the product build
+#if SBM_FAST_TU == 3
+hipError_t launch_sad_fast_pw3(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s) {
+  switch (wsz) {
+    case 29: return launch_nd<29, 1>(a, border, mode, split, s);
+    case 31: return launch_nd<31, 1>(a, border, mode, split, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#elif SBM_FAST_TU == 2
+hipError_t launch_sad_fast_pw3(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s);   // sbm_sad_fast_pw3.hip
+#endif
 #if SBM_FAST_TU == 2 || SBM_FAST_PINGPONG || defined(SBM_DEV_FEW19)
 #if SBM_FAST_TU == 2
 hipError_t launch_sad_fast_pw2(const FastArgs& a, int wsz, bool border, int mode, bool split, hipStream_t s) {
@@ -1368,7 +1381,11 @@ static hipError_t launch_sad_fast_pw2(const FastArgs& a, int wsz, bool border, i
 #endif
     case 19: return launch_nd<19, 1>(a, border, mode, split, s);
     case 23: return launch_nd<23, 1>(a, border, mode, split, s);
+#if SBM_FAST_TU == 2
+    default: return launch_sad_fast_pw3(a, wsz, border, mode, split, s);
+#else
     default: return hipErrorInvalidValue;
+#endif
   }
 }
 #else
@@ -1499,6 +1516,10 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
   switch (g.wsz) {
 #if defined(SBM_DEV_FEW19)
     default: e = launch_sad_fast_pw1(a, g.wsz, border, mode, split, s); break;
+#elif defined(SBM_DEV_FEW31)   // (experiment: windows 29 and 31 as 1-column sums)
+    case 29: e = launch_nd<29, 1>(a, border, mode, split, s); break;
+    case 31: e = launch_nd<31, 1>(a, border, mode, split, s); break;
+    default: e = hipErrorInvalidValue; break;
 #elif defined(SBM_DEV_FEW)   // development builds (tools/exp): only the bench workloads' windows are instantiated
     case 15: e = launch_nd<5, 3>(a, border, mode, split, s); break;
     case 21: e = launch_nd<7, 3>(a, border, mode, split, s); break;
