@@ -43,8 +43,9 @@
  *   SBM_FAST_PFSHIFT    2        once      0 = unscaled prefiltered planes (plain winner search), 1 = at most one tag bit;
  *                                          GPU tests
  *   SBM_FAST_CS3        1        per call  0 = plain column strips only (no column-stride-3 strips); GPU tests
- *   SBM_SPECKLE_LISTS   1        per call  0 = row-walking count / apply kernels of the speckle filter; GPU tests
- *   SBM_SPECKLE_BAND    auto     per call  0 / 2 / 4 / 8 = band height of the speckle filter's band walk (0: round-1 kernels);
+ *   SBM_SPECKLE_LISTS   1        per call  0 = the speckle filter's row-walking kernels (one wavefront per row, per-pixel labels)
+ *                                          instead of the band walk + run records; GPU tests
+ *   SBM_SPECKLE_BAND    auto     per call  2 / 4 = band height of the speckle filter's band walk, 0 = row-walking kernels;
  *                                          GPU tests
  *   SBM_HOST_ZEROCOPY   1        per call  0 = small host-buffer calls (sbm_compute / sbm_compute_batch up to 8 MB of maps) into
  *                                          pageable memory return their maps through a D2H copy + stream synchronisation instead of

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include "sbm_common.h"
 
@@ -27,9 +28,9 @@ struct sbm_handle {
   int cap_n, cap_W, cap_H, cap_pitch;
   uint8_t *pf_l, *pf_r;
   int16_t* disp_pre;
-  int32_t *cost, *labels, *counts;
-  uint32_t* spk_heads;   // compact per-row run-head lists of the speckle filter: cap_n * H * W entries
-  int32_t* spk_nheads;   // cap_n * H
+  int32_t* cost;
+  void* spk_runs;        // speckle filter: 16 bytes per pixel (run records of the band walk / labels + sizes of the row-walking kernels)
+  int32_t* spk_nheads;   // cap_n * H (runs per row)
   uint32_t* spk_seam;    // contacts across band seams (band walk of the speckle filter): cap_n * ceil(H/2) * W entries
   int32_t* spk_nseam;    // cap_n * ceil(H/2)
   uint16_t* vsum;      // column sums of PREFILTER_NORMALIZED_RESPONSE (2 * cap_n * W * H), allocated on first use
@@ -67,7 +68,7 @@ struct sbm_handle {
   static constexpr int kChunks = 64;
   hipEvent_t ev_in[kChunks], ev_done[kChunks];
   bool pipe_ok;
-  char last_kernel[96];   // SAD kernel of the last sbm_compute_device call (sbm_last_kernel_name)
+  char last_kernel[128];   // SAD kernel of the last sbm_compute_device call (sbm_last_kernel_name)
   // last launch (for sbm_debug_fetch)
   Geom last;
   bool have_last;
@@ -118,6 +119,16 @@ extern "C" int sbm_dev_host_prof(double* out8, unsigned long long* calls) {
 #define HP_BEGIN() do { } while (0)
 #define HP(i) do { } while (0)
 #endif
+
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#else
+  std::this_thread::yield();
+#endif
+}
 
 #define HIPCHK(h, call)                         \
   do {                                          \
@@ -185,12 +196,12 @@ const char* sbm_strerror(int code) {
 int sbm_version(void) { return SBM_VERSION_MAJOR * 1000 + SBM_VERSION_MINOR; }
 
 static void free_scratch(sbm_handle* h) {
-  hipFree(h->pf_l); hipFree(h->pf_r); hipFree(h->disp_pre); hipFree(h->cost); hipFree(h->labels); hipFree(h->counts);
-  hipFree(h->spk_heads); hipFree(h->spk_nheads); hipFree(h->spk_seam); hipFree(h->spk_nseam);
-  h->spk_heads = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr; h->spk_nseam = nullptr;
+  hipFree(h->pf_l); hipFree(h->pf_r); hipFree(h->disp_pre); hipFree(h->cost);
+  hipFree(h->spk_runs); hipFree(h->spk_nheads); hipFree(h->spk_seam); hipFree(h->spk_nseam);
+  h->spk_runs = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr; h->spk_nseam = nullptr;
   hipFree(h->vsum);
   h->vsum = nullptr;
-  h->pf_l = h->pf_r = nullptr; h->disp_pre = nullptr; h->cost = h->labels = h->counts = nullptr;
+  h->pf_l = h->pf_r = nullptr; h->disp_pre = nullptr; h->cost = nullptr;
   h->cap_n = h->cap_W = h->cap_H = h->cap_pitch = 0;
 }
 
@@ -232,7 +243,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   const size_t npix = (size_t)h->cap_n * h->cap_W * h->cap_H, plane = (size_t)h->cap_n * h->cap_pitch * h->cap_H;
   size_t b = 2 * plane + npix * 2;
   if (h->cost) b += npix * 4;
-  if (h->labels) b += npix * 14 + (size_t)h->cap_n * h->cap_H * 6;   // labels, counts, head lists, seam lists
+  if (h->spk_runs) b += npix * 18 + (size_t)h->cap_n * h->cap_H * 6;   // run records, seam lists, run / contact counts
   if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
   b += (size_t)h->fq_n * h->fq_W * h->fq_H * 8;
@@ -423,11 +434,9 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
   const size_t npix = (size_t)h->cap_n * W * H;
   if (need_cost && !h->cost) HIPCHK(h, hipMalloc((void**)&h->cost, npix * sizeof(int32_t)));
   if (need_speckle && !h->spk_nseam) {   // keyed on the LAST buffer of the set: an attempt that failed half way is redone
-    hipFree(h->labels); hipFree(h->counts); hipFree(h->spk_heads); hipFree(h->spk_nheads); hipFree(h->spk_seam);
-    h->labels = h->counts = nullptr; h->spk_heads = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr;
-    HIPCHK(h, hipMalloc((void**)&h->labels, npix * sizeof(int32_t)));
-    HIPCHK(h, hipMalloc((void**)&h->counts, npix * sizeof(int32_t)));
-    HIPCHK(h, hipMalloc((void**)&h->spk_heads, npix * sizeof(uint32_t)));
+    hipFree(h->spk_runs); hipFree(h->spk_nheads); hipFree(h->spk_seam);
+    h->spk_runs = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr;
+    HIPCHK(h, hipMalloc(&h->spk_runs, npix * 16));
     HIPCHK(h, hipMalloc((void**)&h->spk_nheads, (size_t)h->cap_n * H * sizeof(int32_t)));
     const size_t seams = (size_t)h->cap_n * ((H + 1) / 2);
     HIPCHK(h, hipMalloc((void**)&h->spk_seam, seams * W * sizeof(uint32_t)));
@@ -506,6 +515,9 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
 
   // 16-bit cost plane when every producer is a 16-bit-sum kernel (fast interior + border kernels, w/2 clamped columns on
   // each side); the generic kernel needs int32
+  // (the once-per-device self-test behind the in-place accumulate runs on THIS handle's stream, before the envelope predicate
+  // below can trigger it on the legacy stream)
+  const bool inplace = mqsad_inplace_ok(h->stream);
   const bool fast = any_rows && sad_fast_supported(g);
   int fa = 0, fb = 0;
   if (fast) {
@@ -550,7 +562,10 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
       }
     } else if (sad_wide_supported(g) && env_switch("SBM_WIDE", 1)) {
       HIPCHK(h, launch_sad_wide(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
-      snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_wide_kernel");
+      // (say so when this configuration only left the interior kernel's envelope because the in-place accumulate is off or
+      // its device self-test failed: windows 29 / 31 and 257..512 disparities are 8-25x slower here, see include/sbm.h)
+      const bool narrowed = !inplace && g.wsz <= 31 && g.nd <= kFastNdMax && (g.wsz > 27 || g.nd > 256);
+      snprintf(h->last_kernel, sizeof(h->last_kernel), narrowed ? "sad_wide_kernel [in-place accumulate unavailable]" : "sad_wide_kernel");
     } else {
       HIPCHK(h, launch_sad_generic(h->pf_l, h->pf_r, h->disp_pre, h->cost, g, 0, g.xend, h->stream));
       snprintf(h->last_kernel, sizeof(h->last_kernel), "sad_generic_kernel");
@@ -560,8 +575,7 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   HIPCHK(h, launch_lrcheck(h->disp_pre, h->cost, out, g, p.disp12_max_diff, h->stream));
   mark(h, 4);
   if (speckle)
-    HIPCHK(h, launch_speckle(out, h->labels, h->counts, h->spk_heads, h->spk_nheads, h->spk_seam, h->spk_nseam, g, p.speckle_window_size, p.speckle_range,
-                             h->stream));
+    HIPCHK(h, launch_speckle(out, h->spk_runs, h->spk_nheads, h->spk_seam, h->spk_nseam, g, p.speckle_window_size, p.speckle_range, h->stream));
   mark(h, 5);
   if (h->instr) h->calls++;
   h->ncall++;
@@ -1095,20 +1109,30 @@ __global__ void __launch_bounds__(256) maps_out_kernel(const uint4* __restrict__
 }
 
 static int ensure_zc(sbm_handle* h, size_t bytes) {
-  if (h->zc_out && h->zc_bytes >= bytes) return SBM_OK;
+  if (h->zc_out && h->zc_flag && h->zc_cnt && h->zc_bytes >= bytes) return SBM_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->zc_out) hipHostFree(h->zc_out);
-  h->zc_out = nullptr; h->zc_bytes = 0;
-  HIPCHK(h, hipHostMalloc((void**)&h->zc_out, bytes + 64, hipHostMallocMapped | hipHostMallocCoherent));
-  h->zc_bytes = bytes;
+  // flag and counter first, the staging last: zc_bytes only ever describes a complete set (a failure half way leaves a state
+  // the next call simply completes)
   if (!h->zc_flag) {
     HIPCHK(h, hipHostMalloc((void**)&h->zc_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
     *h->zc_flag = 0u;
     h->zc_seq = 0u;
   }
   if (!h->zc_cnt) {
-    HIPCHK(h, hipMalloc((void**)&h->zc_cnt, 64));
-    HIPCHK(h, hipMemsetAsync(h->zc_cnt, 0, 64, h->stream));
+    unsigned* cnt = nullptr;
+    HIPCHK(h, hipMalloc((void**)&cnt, 64));
+    const hipError_t e = hipMemsetAsync(cnt, 0, 64, h->stream);
+    if (e != hipSuccess) {
+      hipFree(cnt);
+      HIPCHK(h, e);
+    }
+    h->zc_cnt = cnt;
+  }
+  if (!(h->zc_out && h->zc_bytes >= bytes)) {
+    if (h->zc_out) hipHostFree(h->zc_out);
+    h->zc_out = nullptr; h->zc_bytes = 0;
+    HIPCHK(h, hipHostMalloc((void**)&h->zc_out, bytes + 64, hipHostMallocMapped | hipHostMallocCoherent));
+    h->zc_bytes = bytes;
   }
   return SBM_OK;
 }
@@ -1125,14 +1149,20 @@ static int maps_out_and_wait(sbm_handle* h, const int16_t* d_src, size_t count) 
   hipLaunchKernelGGL(maps_out_kernel, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(h->zc_out), n16,
                      d_src + n16 * 8, h->zc_out + n16 * 8, ntail, h->zc_cnt, h->zc_flag, seq);
   HIPCHK(h, hipGetLastError());
-  // spin on the flag; a stream that has failed never raises it, so fall back to the runtime's own wait after a while
+  // Poll the flag: a short pure spin (a one-pair call ends within tens of microseconds of the launch), then spin with yields
+  // so that a loaded host or many engines driven from many threads do not burn a core each, and after 2 ms the runtime's own
+  // wait -- also the way out when the stream has failed and the flag will never be raised.
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
   while (__atomic_load_n(h->zc_flag, __ATOMIC_ACQUIRE) != seq) {
-    __builtin_ia32_pause();
-    if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      break;
+    cpu_relax();
+    if ((++spins & 0xffu) == 0u) {
+      const auto dt = std::chrono::steady_clock::now() - t0;
+      if (dt > std::chrono::milliseconds(2)) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        break;
+      }
+      if (dt > std::chrono::microseconds(150)) std::this_thread::yield();
     }
   }
   return SBM_OK;

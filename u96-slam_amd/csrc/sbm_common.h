@@ -90,11 +90,11 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
                           int disp12_max_diff, hipStream_t s);
 
-// cv filterSpeckles as parallel connected components (union-find). labels/counts: n*H*W int32 scratch each; heads:
-// n*H*W uint32 and nheads: n*H int32 (compact per-row run-head lists; may be null -> row-walking kernels).
-hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, uint32_t* seam,
-                          int32_t* nseam, const Geom& g,
-                          int max_size, int max_diff, hipStream_t s);
+// cv filterSpeckles as parallel connected components (union-find). runs: 16 bytes per pixel of scratch (run records of the
+// band walk, or the per-pixel labels + sizes of the row-walking kernels); nheads: n*H int32 (runs per row; may be null ->
+// row-walking kernels); seam: n*ceil(H/2)*W uint32, nseam: n*ceil(H/2) int32 (contacts across band seams).
+hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* seam, int32_t* nseam, const Geom& g, int max_size,
+                          int max_diff, hipStream_t s);
 
 // Stand-alone prefilter of dense images (either flavour) and the rectifier in front of it (sbm_rectify.hip).
 hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, int W, int H, int rtl, int cap,

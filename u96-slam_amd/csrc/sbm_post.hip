@@ -285,10 +285,13 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 // ---------------------------------------------------------------------------------------------------------
 // Speckle filter.  cv's raster-order flood fill yields plain 4-connected components of the relation
 // "both != newVal and |a-b| <= maxDiff" (order-independent), so it is computed here as
-// run-based union-find.  Every kernel maps ONE WAVEFRONT TO ONE IMAGE ROW and walks it in 64-pixel chunks; run
-// membership is recomputed from the disparity row with ballots (head = valid pixel not connected to its left
-// neighbour), so only run HEADS own an entry in labels[] (parent pointer) and counts[] (run length, later the
-// component size at the root).  HBM traffic per kernel ~ one or two reads of the int16 plane.
+// run-based union-find, in two implementations:
+//  * default (further down: speckle_band_kernel, _seam_, _count_list_, _apply_list_): a wavefront walks a band of rows,
+//    runs get compact 16-byte records, everything after the walk is driven by those records;
+//  * row-walking kernels (right below; SBM_SPECKLE_BAND=0 / SBM_SPECKLE_LISTS=0, images of 2^27 pixels and more, rows wider
+//    than 65535): ONE WAVEFRONT PER IMAGE ROW walks it in 64-pixel chunks; run membership is recomputed from the disparity
+//    row with ballots (head = valid pixel not connected to its left neighbour), so only run HEADS own an entry in labels[]
+//    (parent pointer) and counts[] (run length, later the component size at the root):
 //   1. runs    heads: labels[head] = head, counts[head] = run length.
 //   2. merge   rows y and y+1 together: the first pixel of every vertical contact between two runs unions them
 //              (atomicMin hooks); later pixels of the same contact are skipped.
@@ -301,36 +304,39 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
 // SCOPE: agent where wavefronts of other workgroups (possibly on another XCD, behind another L2) union into the same
 // labels; workgroup where only the calling wavefront touches them during the kernel (band walk): those atomics are served by
 // the XCD's own L2 instead of going out to the fabric -- several times shorter dependent round trips.
-template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
+// STRIDE: ints between two parent words -- 1 for the per-pixel label plane of the row-walking kernels, 4 for the run records
+// of the band walk (SpkRun::parent).
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT, int STRIDE = 1>
 __device__ __forceinline__ int uf_find(int* L, int i) {
   int r = i;
   for (;;) {
-    const int p = __hip_atomic_load(L + r, __ATOMIC_RELAXED, SCOPE);
+    const int p = __hip_atomic_load(L + (size_t)r * STRIDE, __ATOMIC_RELAXED, SCOPE);
     if (p == r) return r;
-    const int gp = __hip_atomic_load(L + p, __ATOMIC_RELAXED, SCOPE);
+    const int gp = __hip_atomic_load(L + (size_t)p * STRIDE, __ATOMIC_RELAXED, SCOPE);
     if (gp == p) return p;
-    __hip_atomic_fetch_min(L + r, gp, __ATOMIC_RELAXED, SCOPE);
+    __hip_atomic_fetch_min(L + (size_t)r * STRIDE, gp, __ATOMIC_RELAXED, SCOPE);
     r = gp;
   }
 }
 
-template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT, int STRIDE = 1>
 __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   for (;;) {
-    a = uf_find<SCOPE>(L, a);
-    b = uf_find<SCOPE>(L, b);
+    a = uf_find<SCOPE, STRIDE>(L, a);
+    b = uf_find<SCOPE, STRIDE>(L, b);
     if (a == b) return;
     if (a > b) { const int t = a; a = b; b = t; }
-    const int old = __hip_atomic_fetch_min(L + b, a, __ATOMIC_RELAXED, SCOPE);
+    const int old = __hip_atomic_fetch_min(L + (size_t)b * STRIDE, a, __ATOMIC_RELAXED, SCOPE);
     if (old == b) return;
     b = old;
   }
 }
 
 // root lookup once parents are final (after the merge kernel): plain, cacheable loads
+template <int STRIDE = 1>
 __device__ __forceinline__ int uf_root_final(const int* L, int i) {
   int r = i;
-  for (int p = L[r]; p != r; p = L[r]) r = p;
+  for (int p = L[(size_t)r * STRIDE]; p != r; p = L[(size_t)r * STRIDE]) r = p;
   return r;
 }
 
@@ -499,17 +505,38 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
 }
 
 // ---- band walk: runs + merge in one pass ---------------------------------------------------------------------------------
-// One wavefront owns G consecutive rows (a band) and walks them together, chunk by chunk, with the band's next row as a
-// look-ahead: every row is stepped once per chunk instead of three times (once by `runs`, twice by `merge` as the upper and
-// the lower row of a pair), which is what these issue-bound kernels pay for. Contacts between two rows of the band are
-// unioned by the band's own wavefront (nobody else touches the band's labels in this kernel, so the labels written a few
-// instructions earlier are simply ordered by a vmcnt wait); contacts across the seam to the next band are appended to a
-// per-band list (upper head column | lower head column << 16) and unioned by speckle_seam_kernel once every band is done.
+// One wavefront owns G consecutive rows (a band) and walks them together, chunk by chunk (64 columns), with the band's next
+// row as a look-ahead. Contacts between two rows of the band are unioned by the band's own wavefront (nobody else touches the
+// band's runs in this kernel); contacts across the seam to the next band go to a per-band list (upper run | lower run << 16)
+// and are unioned by speckle_seam_kernel once every band is done.
+//
+// Round 6, data: a RUN is the unit of everything downstream, so runs get compact 16-byte records -- run k of row y lives in
+// slot y * W + k of the pair's record plane: parent (union-find), size (accumulated at the root by
+// the count kernel), first and last column. A row of a disparity map holds a handful of runs, so its records share one or two
+// cache lines; the round-5 layout (labels and sizes indexed by the PIXEL of the run head, lists elsewhere) cost a cache line
+// of HBM traffic per run and array -- the unions, the count and the apply kernel were chains of DRAM round trips. The k-th
+// run of a row is the same run for the wavefront that owns the row and for the one that looks ahead into it, so contacts
+// name runs by their index and the walk carries a run COUNT per row instead of the column of the last head.
+// Round 6, walk: built around what a disparity map looks like -- long runs. Per chunk, plain per-lane arithmetic decides
+// whether ANYTHING happens in it: every pixel of every row valid and joined to its left neighbour, every vertical pair in
+// contact (also at the pixel left of the chunk)  =>  no run starts, no run ends, no new contact, no state changes: the chunk
+// costs ~45 vector instructions and the scalar unit nothing (86 % of the chunks of the bench frames; the general path --
+// wavefront-uniform mask algebra, list appends -- runs on the rest). Chunks without a single valid pixel behind such a chunk
+// are skipped likewise.
+//  * Invalid pixels are replaced by a value that is far from every valid one AND from the substitutes of the four
+//    neighbours (it alternates with lane and row parity), so "both valid and |a - b| <= maxDiff" is ONE unsigned compare,
+//    t = a + maxDiff - b <= 2 maxDiff, and the all-quiet test is one v_max3 tree over the t's + one compare.
+//  * The pixel left of the chunk comes from the previous chunk's registers (DPP wave_ror / wave_shr), not from carried
+//    scalar state; run ends are detected at the pixel to their right, so a chunk never owes the next one anything.
+// (Column segments -- several wavefronts per band, a run that crosses a segment edge cut in two and re-joined by the seam
+// kernel -- were built and measured in round 6: the band walk of one pair got shorter by what the seam kernel got longer, and
+// every larger launch lost; profiles/r06_speckle.md.)
+struct SpkRun { int parent, size, first, last; };
 constexpr int SPK_BG = 4;   // chunks loaded up front per row
+constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x10000000;
 
 template <int G>
-__global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, int* __restrict__ labels,
-                                                            int* __restrict__ counts, unsigned* __restrict__ heads,
+__global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
                                                             int* __restrict__ nheads, unsigned* __restrict__ seam,
                                                             int* __restrict__ nseam, int HS, int W, int H, int newval,
                                                             int maxdiff) {
@@ -520,139 +547,178 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: keeps row pointers and counters in SGPRs
   const int band = blockIdx.x * 4 + wave;
   if (band >= nbands) return;
+  constexpr int cs = 0;
+  const int ce = W;
   const int y0 = band * G;
   const size_t plane_off = (size_t)blockIdx.y * W * H;
   const int16_t* d = disp + plane_off;
-  int* L = labels + plane_off;
-  int* C = counts + plane_off;
+  SpkRun* const R = runs + plane_off;
+  int* const P = &R->parent;                                   // parent of slot i: P[4 i]
   int2* const list = contact_lds[wave];
   unsigned* const sl = seam + ((size_t)blockIdx.y * nbands + band) * HS;
   int count = 0, nsm = 0;   // uniform: buffered in-band contacts, seam contacts listed so far
   auto flush = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // label stores of this wavefront have left before the unions start
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // record stores of this wavefront have left before the unions start
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < count; i += 64) {
       const int2 c = list[i];
-      uf_union<__HIP_MEMORY_SCOPE_WORKGROUP>(L, c.x, c.y);
+      uf_union<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, c.x, c.y);
     }
     __builtin_amdgcn_wave_barrier();
     count = 0;
   };
-  RowWalk rw[G + 1];
-  int nh[G], ne[G];           // run starts / run ends listed so far
-  unsigned pend[G];           // 1: the pixel left of the chunk is valid and its run end is not settled yet
-  unsigned prev_cd[G];        // vertical contact between rows r and r+1 at the pixel left of the chunk (0 / 1)
+  const unsigned slot0 = (unsigned)(y0 * W);   // slot of run 0 of the band's first row (rows: + r W)
+  const unsigned tm = 2u * (unsigned)maxdiff;
+  // substitutes of invalid pixels: rows of even / odd parity (bands start on even rows: G is even)
+  const int far_e = kSpkFar + ((lane & 1) ? kSpkFarStep : 0), far_o = kSpkFar + ((lane & 1) ? 0 : kSpkFarStep);
+
+  int nh[G + 1], ne[G];   // uniform: runs started (owned rows and the look-ahead row) / ended so far
 #pragma unroll
-  for (int r = 0; r <= G; r++) rw[r].init(newval);
+  for (int r = 0; r <= G; r++) nh[r] = 0;
 #pragma unroll
-  for (int r = 0; r < G; r++) { nh[r] = 0; ne[r] = 0; pend[r] = 0; prev_cd[r] = 0; }
-  // every array is addressed as (uniform base) + (32-bit byte offset): rows differ by the uniform element offset y * W
-  // (head lists have one row of W slots per image row, so the same offset serves labels, counts and lists)
-  // the row's W list slots (4 bytes each) hold two 16-bit lists: run starts in the first half, run ends in the second
-  unsigned short* const st = reinterpret_cast<unsigned short*>(heads + plane_off);
-  unsigned short* const en = st + W;
-  const unsigned y0W = (unsigned)(y0 * W);        // pixel index of the band's first row; its lists start at element 2 * y0W
+  for (int r = 0; r < G; r++) ne[r] = 0;
+  int vp[G + 1];              // the previous chunk's (substituted) values; its lane 63 is the pixel left of this chunk
+#pragma unroll
+  for (int r = 0; r <= G; r++) vp[r] = (r & 1) ? far_o : far_e;   // a row starts behind a boundary
+  unsigned mvp = 0u;          // the previous chunk's vertical maximum (contact state at the pixel left of the chunk)
+  bool prev_empty = true;     // uniform: the previous chunk held no valid pixel (nothing pending at its right edge)
 
   // Loads and stores share one counter (vmcnt) and may complete out of order, so a wait for a load with stores in flight
-  // is a wait for ALL of them -- a store acknowledgement (~1 us) per chunk when loads are consumed chunk by chunk. Hence:
-  // a group's values are consumed (pinned) before the group's first store, and the next group's loads are issued right
-  // then, so that they are in flight during this group's arithmetic and stores.
+  // is a wait for ALL of them. Hence: a group's values are consumed (pinned) before the group's first store, and the next
+  // group's loads are issued right then, so that they are in flight during this group's arithmetic and stores.
+  // (buffer loads: row offset in an SGPR, chunk offset in the instruction, one VGPR of column offsets per group; columns
+  // beyond the row read the next row or -- beyond the plane -- zero, rows are clamped into the image: such values become
+  // newval when consumed)
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(d), 0, 2 * W * H, 0x00020000);
   int vn[G + 1][SPK_BG];
   auto load_group = [&](int cb0) {
-    // branch-free: columns clamped into the row, rows into the image; out-of-range values become newval when consumed
+    const int vo = 2 * (cb0 + lane);
 #pragma unroll
     for (int r = 0; r <= G; r++) {
-      const unsigned rowoff = (unsigned)(min(y0 + r, H - 1) * W);
+      const int so = 2 * min(y0 + r, H - 1) * W;
 #pragma unroll
-      for (int g = 0; g < SPK_BG; g++) vn[r][g] = (int)*at32(d, rowoff + (unsigned)min(cb0 + 64 * g + lane, W - 1));
+      for (int g = 0; g < SPK_BG; g++) vn[r][g] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rs_d, vo + 128 * g, so, 0);
     }
   };
-  load_group(0);
-  for (int cb0 = 0; cb0 < W; cb0 += 64 * SPK_BG) {
+  load_group(cs);
+  for (int cb0 = cs; cb0 < ce; cb0 += 64 * SPK_BG) {
     int vs[G + 1][SPK_BG];
+    const bool inside = y0 + G < H && cb0 + 64 * SPK_BG <= ce;   // uniform: the whole group lies inside the image
 #pragma unroll
     for (int r = 0; r <= G; r++) {
       const bool row_ok = y0 + r < H;   // uniform
 #pragma unroll
       for (int g = 0; g < SPK_BG; g++) {
-        vs[r][g] = (row_ok && cb0 + 64 * g + lane < W) ? vn[r][g] : newval;
+        vs[r][g] = (inside || (row_ok && cb0 + 64 * g + lane < ce)) ? vn[r][g] : newval;
         asm volatile("" : "+v"(vs[r][g]));   // consumed here, not at the first use further down
       }
     }
-    if (cb0 + 64 * SPK_BG < W) load_group(cb0 + 64 * SPK_BG);
+    if (cb0 + 64 * SPK_BG < ce) load_group(cb0 + 64 * SPK_BG);
 #pragma unroll
     for (int g = 0; g < SPK_BG; g++) {
       const int cb = cb0 + 64 * g;
-      if (cb >= W) break;
-      // phase 1 (straight-line, rows independent: the scheduler interleaves their dependency chains): masks of every row,
-      // first pixels of the vertical contacts of every row pair
+      if (cb >= ce) break;
+      // ---- per-lane arithmetic of every chunk
+      int vq[G + 1], pv[G + 1];
+      unsigned th[G + 1], tv[G + 1];
+      unsigned long long vm[G + 1];
 #pragma unroll
-      for (int r = 0; r <= G; r++) rw[r].step(vs[r][g], cb, lane, newval, maxdiff);
-      unsigned long long fms[G];
-#pragma unroll
-      for (int r = 1; r <= G; r++) {
-        const RowWalk& up = rw[r - 1];
-        const RowWalk& dn = rw[r];
-        // the lower pixel counts as far away when it is invalid, so one compare and the upper row's mask give the contacts
-        const int vd = vs[r][g] != newval ? vs[r][g] : 0x40000000;
-        const unsigned long long cdm = up.valid & __ballot(abs(vs[r - 1][g] - vd) <= maxdiff);
-        const unsigned long long pcdm = (cdm << 1) | prev_cd[r - 1];
-        fms[r - 1] = cdm & (up.head | dn.head | ~pcdm);
-        prev_cd[r - 1] = (unsigned)(cdm >> 63);
+      for (int r = 0; r <= G; r++) {
+        const bool ok = vs[r][g] != newval;
+        vm[r] = __ballot(ok);
+        vq[r] = ok ? vs[r][g] : ((r & 1) ? far_o : far_e);
+        const int a = vq[r] + maxdiff;
+        const int t0 = __builtin_amdgcn_update_dpp(vp[r], vp[r], 0x13C /* wave_ror:1 */, 0xf, 0xf, false);   // lane 0 <- lane 63
+        pv[r] = __builtin_amdgcn_update_dpp(t0, vq[r], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);        // left neighbour
+        th[r] = (unsigned)(a - pv[r]);                    // <= tm: joined to the left neighbour
+        tv[r] = r ? (unsigned)(a - vq[r - 1]) : 0u;       // <= tm: in contact with the pixel above
       }
-      // phase 2: run heads and run ends of the owned rows, appended in column order to the row's two compact lists (the
-      // k-th start and the k-th end belong to the same run). An end is a valid pixel whose right neighbour is a boundary
-      // (a head or an invalid pixel); for lane 63 that neighbour belongs to the next chunk, so it is settled there.
-      // Rows beyond the image hold no valid pixel: nothing happens.
+      unsigned mh = th[0], mv = tv[1];
 #pragma unroll
-      for (int r = 0; r < G; r++) {
-        const unsigned yW = y0W + (unsigned)(r * W);
-        const unsigned long long hm = rw[r].head, bm = hm | ~rw[r].valid;
-        if (pend[r] & (unsigned)bm) {            // (bit 0 of both) the previous chunk's last pixel ended its run
-          if (lane == 0) *at32(en, 2u * yW + (unsigned)ne[r]) = (unsigned short)(cb - 1);
-          ne[r]++;
-        }
-        const unsigned long long em = rw[r].valid & (bm >> 1);
-        if (lane_in(hm)) {
-          const unsigned self = yW + (unsigned)(cb + lane);
-          __hip_atomic_store(at32(L, self), (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          *at32(C, self) = 0;                   // component sizes are accumulated by the count kernel
-          *at32(st, 2u * yW + (unsigned)(nh[r] + lanes_below(hm))) = (unsigned short)(cb + lane);
-        }
-        if (lane_in(em)) *at32(en, 2u * yW + (unsigned)(ne[r] + lanes_below(em))) = (unsigned short)(cb + lane);
-        nh[r] += __popcll(hm);
-        ne[r] += __popcll(em);
-        pend[r] = (unsigned)(rw[r].valid >> 63);
+      for (int r = 1; r <= G; r++) mh = max(mh, th[r]);
+#pragma unroll
+      for (int r = 2; r <= G; r++) mv = max(mv, tv[r]);
+      // contact state left of the chunk: lanes 0..3 see the previous chunk's lanes 63, 0, 1, 2 (conservative: a chunk that
+      // is declined here is simply walked in full)
+      const unsigned ml = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mvp, 0x13C, 0x1, 0x1, false);
+      const bool quiet = __ballot(max(max(mh, mv), ml) > tm) == 0ull;
+      bool empty = false;
+      if (!quiet) {
+        unsigned long long anyv = vm[0];
+#pragma unroll
+        for (int r = 1; r <= G; r++) anyv |= vm[r];
+        empty = anyv == 0ull;
       }
-      // phase 3: list the contacts (in-band: LDS, unioned at the next flush; seam: the band's global list)
+      if (!quiet && !(empty && prev_empty)) {
+        // ---- general path. Run heads of every row; the vertical contacts first (a lane's run is the row's count of runs
+        // before this chunk + the heads at or below the lane), then the records of the owned rows.
+        unsigned long long head[G + 1];
 #pragma unroll
-      for (int r = 1; r <= G; r++) {
-        const unsigned long long fm = fms[r - 1];
-        if (fm) {
-          const unsigned yW = y0W + (unsigned)(r * W);
-          if (lane_in(fm)) {
-            const int k = lanes_below(fm);
-            const int su = rw[r - 1].start(lane), sd = rw[r].start(lane);
-            if (r < G) list[count + k] = make_int2((int)(yW - (unsigned)W) + su, (int)yW + sd);
-            else *at32(sl, (unsigned)(nsm + k)) = (unsigned)su | ((unsigned)sd << 16);
+        for (int r = 0; r <= G; r++) head[r] = vm[r] & __ballot(th[r] > tm);
+        auto run_of = [&](int r) -> int {   // index of the lane's run within its row; valid lanes only
+          return nh[r] - 1 + lanes_below(head[r]) + (int)((head[r] >> lane) & 1ull);
+        };
+#pragma unroll
+        for (int r = 1; r <= G; r++) {
+          const unsigned long long cdm = __ballot(tv[r] <= tm);
+          const unsigned long long pcdm = __ballot((unsigned)(pv[r] + maxdiff - pv[r - 1]) <= tm);   // the same, one pixel left
+          // first pixel of a contact between two runs: not the same two runs as at the pixel to the left
+          const unsigned long long fm = cdm & (head[r - 1] | head[r] | ~pcdm);
+          if (fm) {
+            if (lane_in(fm)) {
+              const int k = lanes_below(fm);
+              const int ku = run_of(r - 1), kd = run_of(r);
+              if (r < G) list[count + k] = make_int2((int)(slot0 + (unsigned)((r - 1) * W)) + ku, (int)(slot0 + (unsigned)(r * W)) + kd);
+              else *at32(sl, (unsigned)(nsm + k)) = (unsigned)ku | ((unsigned)kd << 16);
+            }
+            if (r < G) count += __popcll(fm);
+            else nsm += __popcll(fm);
           }
-          if (r < G) count += __popcll(fm);
-          else nsm += __popcll(fm);
         }
-      }
+        // run records of the owned rows, in column order: a head opens the row's next record, a boundary pixel (a head or an
+        // invalid pixel) right of a valid one closes the oldest open one -- the k-th start and the k-th end are the same run.
 #pragma unroll
-      for (int r = 0; r < G; r++) rw[r].next(vs[r][g]);
-      rw[G].next(vs[G][g]);
-      if (count > SPK_BCAP - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
+        for (int r = 0; r < G; r++) {
+          const unsigned rs = slot0 + (unsigned)(r * W);
+          const unsigned long long hm = head[r];
+          const unsigned long long em = __ballot(pv[r] < kSpkFarMin) & (hm | ~vm[r]);
+          if (hm) {
+            if (lane_in(hm)) {
+              const unsigned self = rs + (unsigned)(nh[r] + lanes_below(hm));
+              int* q = &at32(R, self)->parent;
+              // parent = self, size = 0 (accumulated by the count kernel), first column; the last column follows when the run ends
+              __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              q[1] = 0;
+              q[2] = cb + lane;
+            }
+          }
+          if (em) {
+            if (lane_in(em)) at32(R, rs + (unsigned)(ne[r] + lanes_below(em)))->last = cb + lane - 1;
+            ne[r] += __popcll(em);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r <= G; r++) nh[r] += __popcll(head[r]);
+        if (count > SPK_BCAP - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
+      }
+      prev_empty = !quiet && empty;
+#pragma unroll
+      for (int r = 0; r <= G; r++) vp[r] = vq[r];
+      mvp = mv;
     }
+  }
+  // runs that reach the row's last column end there (a chunk-aligned row end has no boundary lane behind it)
+  unsigned tail = 0u;
+  if (((ce - cs) & 63) == 0) {
+#pragma unroll
+    for (int r = 0; r < G; r++) tail |= (__builtin_amdgcn_readlane(vp[r], 63) < kSpkFarMin ? 1u : 0u) << r;
   }
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < G; r++) {
       const int y = y0 + r;
       if (y < H) {
-        const unsigned yW = y0W + (unsigned)(r * W);
-        if (pend[r]) *at32(en, 2u * yW + (unsigned)ne[r]) = (unsigned short)(W - 1);   // W a multiple of 64: the row's last pixel
+        if ((tail >> r) & 1u) at32(R, slot0 + (unsigned)(r * W + ne[r]))->last = ce - 1;
         nheads[(size_t)blockIdx.y * H + y] = nh[r];
       }
     }
@@ -662,7 +728,7 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
 }
 
 // seam contacts of the band walk: one wavefront per band, 64 unions at a time
-__global__ void __launch_bounds__(256) speckle_seam_kernel(int* __restrict__ labels, const unsigned* __restrict__ seam,
+__global__ void __launch_bounds__(256) speckle_seam_kernel(SpkRun* __restrict__ runs, const unsigned* __restrict__ seam,
                                                             const int* __restrict__ nseam, int HS, int W, int H, int G) {
   const int lane = threadIdx.x & 63;
   const int nbands = (H + G - 1) / G;
@@ -670,12 +736,12 @@ __global__ void __launch_bounds__(256) speckle_seam_kernel(int* __restrict__ lab
   if (band >= nbands) return;
   const int y = band * G + G - 1;   // upper row of the seam
   if (y + 1 >= H) return;
-  int* L = labels + (size_t)blockIdx.y * W * H;
+  int* const P = &(runs + (size_t)blockIdx.y * W * H)->parent;
   const unsigned* sl = seam + ((size_t)blockIdx.y * nbands + band) * HS;
   const int n = nseam[(size_t)blockIdx.y * nbands + band];
   for (int i = lane; i < n; i += 64) {
     const unsigned e = sl[i];
-    uf_union(L, y * W + (int)(e & 0xffffu), (y + 1) * W + (int)(e >> 16));
+    uf_union<__HIP_MEMORY_SCOPE_AGENT, 4>(P, y * W + (int)(e & 0xffffu), (y + 1) * W + (int)(e >> 16));
   }
 }
 
@@ -788,95 +854,82 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
   }
 }
 
-// ---- list-driven count / apply: one wavefront per row, one lane per run of the row's compact lists (band walk) -----------
-// (run k of a row: columns starts[k] .. ends[k], two 16-bit lists in the row's W four-byte slots)
-__global__ void __launch_bounds__(256) speckle_count_list_kernel(int* __restrict__ labels, int* __restrict__ counts,
-                                                                  const unsigned* __restrict__ heads,
-                                                                  const int* __restrict__ nheads, int HS, int W, int H,
+// ---- record-driven count / apply: one wavefront per image row, one lane per run -----------------------------------------
+__global__ void __launch_bounds__(256) speckle_count_list_kernel(SpkRun* __restrict__ runs, const int* __restrict__ nheads,
+                                                                  int W, int H, int maxsize) {
+  SPK_ROW_SETUP
+  if (y >= H) return;
+  SpkRun* const R = runs + plane_off;
+  int* const P = &R->parent;
+  const int nh = nheads[(size_t)blockIdx.y * H + y];
+  for (int i = lane; i < nh; i += 64) {
+    const int self = y * W + i;
+    const int4 rec = *reinterpret_cast<const int4*>(R + self);   // parent, size, first, last
+    int r = rec.x;
+    if (r != self) {
+      r = uf_root_final<4>(P, r);
+      if (r != rec.x) P[4 * (size_t)self] = r;   // parents are final: point straight at the root so the apply kernel's lookup is one step
+    }
+    // every run adds its length to the root's (zero-initialised) size, unless the component is already known to exceed
+    // maxSpeckleSize (saturating: exact where it matters, no contention on large components)
+    int* const sz = P + 4 * (size_t)r + 1;
+    if (__hip_atomic_load(sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(sz, rec.w - rec.z + 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __restrict__ disp, const SpkRun* __restrict__ runs,
+                                                                  const int* __restrict__ nheads, int W, int H, int newval,
                                                                   int maxsize) {
   SPK_ROW_SETUP
   if (y >= H) return;
-  int* L = labels + plane_off;
-  int* C = counts + plane_off;
-  const size_t row = (size_t)blockIdx.y * H + y;
-  const unsigned short* st = reinterpret_cast<const unsigned short*>(heads + row * HS);
-  const unsigned short* en = st + W;
-  const int nh = nheads[row];
-  for (int i = lane; i < nh; i += 64) {
-    const int x = st[i], len = (int)en[i] - x + 1;
-    const int self = y * W + x;
-    const int r = uf_root_final(L, self);
-    if (r != self) L[self] = r;   // parents are final: point straight at the root so the apply kernel's lookup is one step
-    // every run adds its length to the root's (zero-initialised) count, unless the component is already known to exceed
-    // maxSpeckleSize (saturating: exact where it matters, no contention on large components)
-    if (__hip_atomic_load(C + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(C + r, len);
-  }
-}
-
-__global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __restrict__ disp, const int* __restrict__ labels,
-                                                                  const int* __restrict__ counts,
-                                                                  const unsigned* __restrict__ heads,
-                                                                  const int* __restrict__ nheads, int HS, int W, int H,
-                                                                  int newval, int maxsize) {
-  SPK_ROW_SETUP
-  if (y >= H) return;
   int16_t* d = disp + plane_off + (size_t)y * W;
-  const int* L = labels + plane_off;
-  const int* C = counts + plane_off;
-  const size_t row = (size_t)blockIdx.y * H + y;
-  const unsigned short* st = reinterpret_cast<const unsigned short*>(heads + row * HS);
-  const unsigned short* en = st + W;
-  const int nh = nheads[row];
+  const SpkRun* const R = runs + plane_off;
+  const int nh = nheads[(size_t)blockIdx.y * H + y];
   for (int i = lane; i < nh; i += 64) {
-    const int x = st[i], xe = en[i];
-    if (C[uf_root_final(L, y * W + x)] <= maxsize)          // a speckle: its runs are at most maxsize long
-      for (int j = x; j <= xe; j++) d[j] = (int16_t)newval;
+    const int self = y * W + i;
+    const int4 rec = *reinterpret_cast<const int4*>(R + self);
+    const int root = rec.x == self ? self : uf_root_final<4>(&R->parent, rec.x);
+    const int size = root == self ? rec.y : R[root].size;
+    if (size <= maxsize)          // a speckle: its runs are at most maxsize long
+      for (int j = rec.z; j <= rec.w; j++) d[j] = (int16_t)newval;
   }
 }
 
-hipError_t launch_speckle(int16_t* disp, int32_t* labels, int32_t* counts, uint32_t* heads, int32_t* nheads, uint32_t* seam,
-                          int32_t* nseam, const Geom& g, int max_size, int max_diff, hipStream_t s) {
+hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* seam, int32_t* nseam, const Geom& g, int max_size,
+                          int max_diff, hipStream_t s) {
   dim3 grid((g.H + 3) / 4, g.n);
   max_diff = std::min(max_diff, 1 << 17);   // int16 values: any larger range joins everything alike
-  const int HS = g.W;   // list slots per row: adjacent valid pixels further apart than maxDiff are separate runs, up to W per row
-  // Two implementations. Default: band walk (runs + merge in one pass, G rows per wavefront) + seam unions, then count and
-  // apply driven by the rows' compact run lists (16-bit columns: W <= 65535; 32-bit byte offsets within an image).
-  // Fallback (SBM_SPECKLE_LISTS=0 or SBM_SPECKLE_BAND=0, or outside those limits): four kernels that each walk the rows.
+  const int HS = g.W;   // seam-list slots per band: at most one contact per pixel of the seam
+  // Two implementations. Default: band walk (runs + merge in one pass, G rows per wavefront) + seam unions,
+  // then count and apply driven by the rows' run records (16-bit run indices: W <= 65535; 32-bit byte offsets within an image's
+  // record plane). Fallback (SBM_SPECKLE_LISTS=0 or SBM_SPECKLE_BAND=0, or outside those limits): four kernels that each walk
+  // the rows, per-pixel labels and sizes carved from the same scratch.
   // (read per call, ~0.1 us each: the GPU tests flip them between calls of one process to compare every variant with the CPU restatement)
   const int lists_env = env_switch("SBM_SPECKLE_LISTS", 1);
   const int band_env = env_switch("SBM_SPECKLE_BAND", -1);
-  const bool lists = heads && nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 30) && lists_env != 0 &&
-                     band_env != 0;
-  int G = 0;
+  const bool lists = nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 27) && lists_env != 0 && band_env != 0;
   if (lists) {
-    // measured (KITTI x64, 640x480 x64, UHD x4, KITTI x1): 4 rows per wavefront once that still leaves >= 4 wavefronts per
-    // SIMD, else 2 (the walk of a band is a serial chain; 8 rows per wavefront was never the fastest). SBM_SPECKLE_BAND=2/4/8
-    // forces a band height.
-    G = (long)g.n * g.H >= 16384 ? 4 : 2;
-    if (band_env == 2 || band_env == 4 || band_env == 8) G = band_env;
-  }
-  if (G) {
+    SpkRun* R = static_cast<SpkRun*>(runs);
+    // 4 rows per wavefront once that still leaves ~6 000 band wavefronts (6 per SIMD), else 2: the walk of a band is a serial
+    // chain and the look-ahead row costs 1/G (profiles/r06_speckle.md; 8 rows never won). SBM_SPECKLE_BAND=2/4 forces a height.
+    int G = (long)g.n * g.H >= 24000 ? 4 : 2;
+    if (band_env == 2 || band_env == 4) G = band_env;
     const int nbands = (g.H + G - 1) / G;
     dim3 bgrid((nbands + 3) / 4, g.n);
-    if (G == 8)
-      hipLaunchKernelGGL(speckle_band_kernel<8>, bgrid, dim3(256), 0, s, disp, labels, counts, heads, nheads, seam, nseam, HS,
-                         g.W, g.H, g.filtered, max_diff);
-    else if (G == 4)
-      hipLaunchKernelGGL(speckle_band_kernel<4>, bgrid, dim3(256), 0, s, disp, labels, counts, heads, nheads, seam, nseam, HS,
-                         g.W, g.H, g.filtered, max_diff);
+    if (G == 4)
+      hipLaunchKernelGGL(speckle_band_kernel<4>, bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, HS, g.W, g.H, g.filtered,
+                         max_diff);
     else
-      hipLaunchKernelGGL(speckle_band_kernel<2>, bgrid, dim3(256), 0, s, disp, labels, counts, heads, nheads, seam, nseam, HS,
-                         g.W, g.H, g.filtered, max_diff);
-    hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, labels, seam, nseam, HS, g.W, g.H, G);
+      hipLaunchKernelGGL(speckle_band_kernel<2>, bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, HS, g.W, g.H, g.filtered,
+                         max_diff);
+    hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, R, seam, nseam, HS, g.W, g.H, G);
+    hipLaunchKernelGGL(speckle_count_list_kernel, grid, dim3(256), 0, s, R, nheads, g.W, g.H, max_size);
+    hipLaunchKernelGGL(speckle_apply_list_kernel, grid, dim3(256), 0, s, disp, R, nheads, g.W, g.H, g.filtered, max_size);
   } else {
+    int* labels = static_cast<int*>(runs);
+    int* counts = labels + (size_t)g.n * g.W * g.H;
     hipLaunchKernelGGL(speckle_runs_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff);
     hipLaunchKernelGGL(speckle_merge_kernel, grid, dim3(256), 0, s, disp, labels, g.W, g.H, g.filtered, max_diff);
-  }
-  if (lists) {
-    hipLaunchKernelGGL(speckle_count_list_kernel, grid, dim3(256), 0, s, labels, counts, heads, nheads, HS, g.W, g.H, max_size);
-    hipLaunchKernelGGL(speckle_apply_list_kernel, grid, dim3(256), 0, s, disp, labels, counts, heads, nheads, HS, g.W, g.H,
-                       g.filtered, max_size);
-  } else {
     hipLaunchKernelGGL(speckle_count_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,
                        max_size);
     hipLaunchKernelGGL(speckle_apply_kernel, grid, dim3(256), 0, s, disp, labels, counts, g.W, g.H, g.filtered, max_diff,

@@ -1234,14 +1234,14 @@ int sad_fast_pfshift(const Geom& g) {
   if (2 * (f * (maxs * g.uniq / 100 + 1)) >= 65535) return 0;
   if ((long)g.tex * f > 0x3fffffff) return 0;
   return sh == (g.wsz <= 15 ? 2 : 1) ? sh : 0;
-  return 0;
 }
 
 bool sad_fast_borders_in_launch(const Geom& g) { return g.nd <= 256; }
 
 bool sad_fast_supported(const Geom& g) {
   if (g.wsz < 5 || g.wsz > 31) return false;   // every odd window 5..31: multiples of 3 with 3-column sums, the rest 1-column
-  if (g.wsz > 27 && !mqsad_inplace_ok(nullptr)) return false;   // (29 and 31 are not in the two-accumulator fallback build)   // every odd window 5..27: multiples of 3 with 3-column sums, the rest 1-column
+  // (mqsad_inplace_ok: cached per device; sbm_compute_device has primed it on the handle's stream before it asks here)
+  if (g.wsz > 27 && !mqsad_inplace_ok(nullptr)) return false;   // 29 and 31 are not in the two-accumulator fallback build
   if (g.nd > kFastNdMax) return false;
   // beyond 256 disparities: three / four cooperating 128-disparity wavefronts (not in the two-accumulator fallback build);
   // their border columns come from the sliding-sum kernel (sbm_sad_wide.hip) in launches of their own

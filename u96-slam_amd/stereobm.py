@@ -207,11 +207,20 @@ class StereoBM:
     def create(numDisparities=0, blockSize=21, device=0):
         return StereoBM(numDisparities, blockSize, device)
 
-    def __del__(self):
+    def close(self):
+        """Release the engine. Outstanding submit_host() submissions are drained first (sbm_synchronize) while their arrays are
+        still referenced here, so every submitted `disparity` array is filled -- sbm_destroy on its own would let the queued
+        copies finish and DROP the maps of the newest submission (include/sbm.h, "sbm_destroy() and the asynchronous feed")."""
         h = getattr(self, "_h", None)
         if h:
+            if getattr(self, "_host_inflight", None):
+                self._L.sbm_synchronize(h)
+                self._host_inflight.clear()
             self._L.sbm_destroy(h)
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     # ---- the cv::StereoBM / cv::StereoMatcher setters and getters -------------------------------------------
     def _set(self, name, v):
@@ -301,7 +310,8 @@ class StereoBM:
 
     def submit_host(self, left, right, disparity):
         """sbm_submit_dense: queue one dense (n,H,W) uint8 batch in (pinned) host memory; `disparity` (n,H,W) int16 is filled
-        when the matching wait_host() returns. At most three submissions are in flight."""
+        when the matching wait_host() returns. At most three submissions are in flight. Dropping the engine with submissions
+        outstanding drains them first (close()); the bare C call sbm_destroy() would drop the newest submission's maps."""
         for a, dt in ((left, np.uint8), (right, np.uint8), (disparity, np.int16)):
             if not isinstance(a, np.ndarray) or a.dtype != dt or a.ndim != 3 or not a.flags.c_contiguous:
                 raise StereoBMError(-2, "submit_host takes C-contiguous (n,H,W) arrays: uint8 images, int16 disparity")
