@@ -43,7 +43,12 @@ class StereoBM {
     return std::shared_ptr<StereoBM>(new StereoBM(numDisparities, blockSize, device));
   }
 
-  ~StereoBM() { sbm_destroy(h_); }
+  // (outstanding computeAsync() calls are drained first: sbm_destroy alone lets the queued copies finish and DROPS the newest
+  // submission's maps -- include/sbm.h, "sbm_destroy() and the asynchronous feed")
+  ~StereoBM() {
+    if (pending_ > 0) sbm_synchronize(h_);
+    sbm_destroy(h_);
+  }
   StereoBM(const StereoBM&) = delete;
   StereoBM& operator=(const StereoBM&) = delete;
 
@@ -77,6 +82,24 @@ class StereoBM {
                size_t dstep) {
     check(sbm_compute(h_, left, lstep, right, rstep, width, height, disp, dstep));
   }
+
+  // Opt-in asynchronous form for callers that keep frames in flight (double buffering), e.g. a capture loop that fetches frame
+  // k+1 while frame k is matched: computeAsync() queues one DENSE pair (stride == width; left / right / disp should be pinned,
+  // hipHostMalloc / hipHostRegister, and must stay valid until the matching wait() returns) and returns at once -- the inputs of
+  // this call cross PCIe while the previous call computes and the one before sends its map home. wait() blocks until the OLDEST
+  // outstanding call has delivered its map. At most three calls are in flight (a fourth computeAsync() first waits for the oldest).
+  // The reference's own loop (main.cpp:201-216: compute, then use the map) keeps calling compute().
+  void computeAsync(const uint8_t* left, const uint8_t* right, int width, int height, int16_t* disp) {
+    check(sbm_submit_dense(h_, 1, left, right, width, height, disp));
+    if (pending_ < 3) pending_++;
+  }
+  void wait() {
+    if (pending_ > 0) {
+      check(sbm_wait_oldest(h_));
+      pending_--;
+    }
+  }
+  int pending() const { return pending_; }
 
 #ifdef SBM_HAVE_OPENCV
   void setROI1(cv::Rect r) { setROI1(r.x, r.y, r.width, r.height); }
@@ -117,7 +140,7 @@ class StereoBM {
   }
 
  private:
-  StereoBM(int nd, int bs, int device) : h_(nullptr) {
+  StereoBM(int nd, int bs, int device) : h_(nullptr), pending_(0) {
     sbm_params_default(&p_, nd, bs);
     check(sbm_create(&h_, &p_, device));
   }
@@ -132,6 +155,7 @@ class StereoBM {
   }
   sbm_params p_;
   sbm_handle* h_;
+  int pending_;   // computeAsync() calls whose wait() is still due
 };
 
 }  // namespace sbm

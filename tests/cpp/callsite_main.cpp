@@ -6,7 +6,9 @@
 // overload is what computes (compile with -DSBM_TEST_WITH_OPENCV): plain cv::Mat destination, a fixed CV_32F destination
 // and the error -> cv::Exception mapping.
 //
-//   callsite_main <width> <height> <nframes> <left.raw> <right.raw> <disp_out.raw>
+//   callsite_main <width> <height> <nframes> <left.raw> <right.raw> <disp_out.raw> [async]
+//
+// "async": ONE matcher outside the loop and the opt-in computeAsync() / wait() pair of the adaptor, two frames in flight.
 //
 // left/right hold nframes dense frames; disp_out receives nframes dense int16 maps. Exit code 0 on success.
 #include <cstdio>
@@ -24,14 +26,25 @@ static bool read_all(const char* path, std::vector<uint8_t>& buf) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 7) return 2;
+  if (argc != 7 && argc != 8) return 2;
+  const bool async = argc == 8;
   const int W = std::atoi(argv[1]), H = std::atoi(argv[2]), N = std::atoi(argv[3]);
   const size_t npix = (size_t)W * H;
   std::vector<uint8_t> left(npix * N), right(npix * N);
   std::vector<int16_t> disp(npix * N);
   if (!read_all(argv[4], left) || !read_all(argv[5], right)) return 3;
   try {
-    for (int i = 0; i < N; i++) {                                     // while(1) of main.cpp:149
+    if (async) {
+      auto bm = sbm::StereoBM::create(64, 21);
+      bm->setPreFilterCap(31); bm->setMinDisparity(0); bm->setTextureThreshold(10); bm->setUniquenessRatio(10);
+      bm->setSpeckleWindowSize(50); bm->setSpeckleRange(32); bm->setDisp12MaxDiff(1);
+      for (int i = 0; i < N; i++) {
+        if (bm->pending() == 2) bm->wait();                          // frame i-2 is complete: its map may be consumed here
+        bm->computeAsync(left.data() + i * npix, right.data() + i * npix, W, H, disp.data() + i * npix);
+      }
+      // the matcher goes out of scope with up to two frames outstanding: its destructor drains them
+    }
+    for (int i = 0; i < N && !async; i++) {                           // while(1) of main.cpp:149
       // --- main.cpp:198-212, cv::StereoBM -> sbm::StereoBM ---------------------------------------------------------
       auto bm = sbm::StereoBM::create(16, 9);
       bm->setROI1(0, 0, 0, 0);                                       // cv::Rect roi1, roi2 are empty (main.cpp:199-203)

@@ -165,12 +165,14 @@ def test_small_host_call_paths_agree(pkg, oracle, torch_cuda, monkeypatch, zc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(400, 90, 128, 15, 3, 0), (640, 120, 64, 21, 1, 0), (420, 80, 112, 15, 5, 0), (500, 90, 192, 21, 2, 0),
-                                   (400, 90, 128, 19, 2, 0), (640, 120, 256, 21, 2, 0), (360, 80, 48, 11, 1, -8), (400, 90, 64, 27, 3, 4)])
+                                   (400, 90, 128, 19, 2, 0), (640, 120, 256, 21, 2, 0), (360, 80, 48, 11, 1, -8), (400, 90, 64, 27, 3, 4),
+                                   (800, 60, 400, 9, 2, 0), (900, 66, 512, 27, 1, 0)])
 def test_filtered_pixels_store_cost_ffff(pkg, torch_cuda, shape):
     """The range-test-free path of lrcheck16_kernel relies on an invariant that spans files: every producer of the
     16-bit cost plane -- LDS-direct strips of every layout, border wavefronts -- stores cost 0xffff with every FILTERED pixel
     of the computed region [lofs, lofs + xend) x [row0, row1) and real costs <= 65534. Checked directly here, not through a
-    downstream mismatch: single-wavefront, cooperating, masked-count and one-pair (split) layouts, 1- and 3-column sums."""
+    downstream mismatch: single-wavefront, cooperating, masked-count and one-pair (split) layouts, 1- and 3-column sums, and --
+    beyond 256 disparities -- the border columns that sbm_sad_wide.hip writes into the same 16-bit plane."""
     from u96_slam_amd import synth
 
     W, H, nd, w, n, mind = shape
@@ -189,3 +191,50 @@ def test_filtered_pixels_store_cost_ffff(pkg, torch_cuda, shape):
     assert bm.last_kernel().startswith("sad_fast_kernel"), bm.last_kernel()
     assert ((p == filtered) == (c == 0xFFFF)).all(), (int(((p == filtered) & (c != 0xFFFF)).sum()), int(((p != filtered) & (c == 0xFFFF)).sum()))
     assert (c[p != filtered] <= 65534).all() and (p != filtered).mean() > 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("outstanding", [1, 2, 3])
+def test_destroy_with_outstanding_submissions(pkg, oracle, torch_cuda, outstanding):
+    """The contract of sbm_destroy() and the asynchronous feed (include/sbm.h): copies that are already queued
+    finish, the NEWEST submission's maps are dropped, and destroy never starts a write into caller memory -- checked through
+    the bare C-ABI with 1, 2 and 3 submissions nobody waited for. The Python mirror's close() (and the C++ adaptor's
+    destructor) drain first, so nothing is dropped there."""
+    import ctypes
+    import torch
+    from u96_slam_amd import synth, stereobm
+
+    W, H, nd, B = 200, 64, 32, 2
+    Lb = stereobm.load_library()
+    prm = stereobm.SbmParams()
+    Lb.sbm_params_default(ctypes.byref(prm), nd, 9)
+    prm.uniqueness_ratio, prm.disp12_max_diff = 10, 1
+    op = oracle.make_params(nd, 9, 31, 0, 10, 10, 0, 0, 1)
+    h = ctypes.c_void_p()
+    assert Lb.sbm_create(ctypes.byref(h), ctypes.byref(prm), 0) == 0
+    sentinel = 12345
+    subs = []
+    for k in range(outstanding):
+        L, R = synth.make_batch(50 * k, B, W, H, nd)
+        hl, hr = torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()
+        hd = torch.full((B, H, W), sentinel, dtype=torch.int16).pin_memory()
+        assert Lb.sbm_submit_dense(h, B, hl.data_ptr(), hr.data_ptr(), W, H, hd.data_ptr()) == 0
+        subs.append((L, R, hl, hr, hd))
+    Lb.sbm_destroy(h)                                  # nobody waited
+    torch.cuda.synchronize()
+    for k, (L, R, hl, hr, hd) in enumerate(subs):
+        if k < outstanding - 1:                        # followed by another submission: its copy was queued and has finished
+            assert np.array_equal(hd.numpy(), oracle.compute_batch(op, L, R)), k
+        else:                                          # the newest: dropped, untouched
+            assert (hd.numpy() == sentinel).all(), k
+    # the parked handle is re-armed by the next create: nothing from the old life writes into the dropped destination
+    bm = pkg.StereoBM.create(nd, 9)
+    bm.setUniquenessRatio(10); bm.setDisp12MaxDiff(1)
+    L, R = subs[-1][0], subs[-1][1]
+    assert np.array_equal(bm.compute(L, R), oracle.compute_batch(op, L, R))
+    assert (subs[-1][4].numpy() == sentinel).all()
+    # ... and the mirror's close() drains: a submission followed by close() IS delivered
+    out = torch.full((B, H, W), sentinel, dtype=torch.int16).pin_memory()
+    bm.submit_host(subs[-1][2].numpy(), subs[-1][3].numpy(), out.numpy())
+    bm.close()
+    assert np.array_equal(out.numpy(), oracle.compute_batch(op, L, R))

@@ -514,6 +514,28 @@ def test_cpp_call_site_three_frames_matches_oracle(tmp_path, pkg, oracle, golden
 
 
 @pytest.mark.gpu
+def test_cpp_compute_async_two_frames_in_flight(tmp_path, pkg, oracle, golden):
+    """The adaptor's opt-in computeAsync() / wait() pair (one matcher, two frames in flight, the destructor drains the rest):
+    five frames, every map equal to the oracle's."""
+    import subprocess
+
+    exe, r = _build_callsite(tmp_path, pkg)
+    assert r.returncode == 0, r.stderr
+    L0, R0 = golden["rect_l"], golden["rect_r"]
+    frames_l = np.stack([np.roll(L0, k, axis=1) for k in range(5)])
+    frames_r = np.stack([np.roll(R0, k, axis=1) for k in range(5)])
+    (tmp_path / "l.raw").write_bytes(frames_l.tobytes())
+    (tmp_path / "r.raw").write_bytes(frames_r.tobytes())
+    run = subprocess.run([str(exe), "640", "480", "5", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(tmp_path / "d.raw"), "async"],
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    got = np.frombuffer((tmp_path / "d.raw").read_bytes(), np.int16).reshape(5, 480, 640)
+    p = oracle.make_params(64, 21, 31, 0, 10, 10, 50, 32, 1)
+    for i in range(5):
+        assert np.array_equal(got[i], oracle.compute(p, frames_l[i], frames_r[i])), i
+
+
+@pytest.mark.gpu
 def test_cpp_inputarray_overload_compiles_and_runs(tmp_path, pkg, oracle, golden):
     """The cv::InputArray / cv::OutputArray overload of sbm::StereoBM::compute -- what the INTEGRATION.md diff at
     main.cpp:201-215 relies on -- compiled and run: against the real OpenCV headers where a box has them, otherwise against

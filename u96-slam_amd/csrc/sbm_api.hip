@@ -1088,22 +1088,29 @@ int sbm_submit_dense(sbm_handle* h, int n, const uint8_t* left, const uint8_t* r
 // stream synchronisation behind it another ~15 (profiles/r05_host_attrib.txt). Instead the last kernel of the call copies the
 // maps into pinned, device-mapped host memory and raises a sequence flag there (last workgroup done, system-scope release);
 // the host spins on the flag and copies the rows to the caller itself.
-__global__ void __launch_bounds__(256) maps_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, const int16_t* __restrict__ src_tail,
-                                                       int16_t* __restrict__ dst_tail, int ntail, unsigned* cnt, unsigned* flag, unsigned seq) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+// The maps leave in up to kZcChunks contiguous chunks, each with its own arrival counter and flag: the host copies chunk k to
+// the caller while the chunks behind it are still crossing PCIe (round 6: the 25 us CPU copy of a 640x480 map used to START
+// when the last byte had landed).
+constexpr int kZcChunks = 8;
+__global__ void __launch_bounds__(256) maps_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, size_t per_chunk, int bpc,
+                                                       const int16_t* __restrict__ src_tail, int16_t* __restrict__ dst_tail, int ntail, unsigned* cnt,
+                                                       unsigned* flag, unsigned seq) {
+  const int c = blockIdx.x / bpc, bi = blockIdx.x - c * bpc;   // chunk, block within the chunk
+  const size_t lo = (size_t)c * per_chunk, hi = lo + per_chunk < n16 ? lo + per_chunk : n16;
+  for (size_t i = lo + (size_t)bi * 256 + threadIdx.x; i < hi; i += (size_t)bpc * 256) {
     const uint4 v = src[i];
     __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
     __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
   }
-  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  if (blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];   // (the last chunk's last block)
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (done == gridDim.x) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned done = __hip_atomic_fetch_add(cnt + c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (done == (unsigned)bpc) {
+      __hip_atomic_store(cnt + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
-      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(flag + c, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1115,7 +1122,7 @@ static int ensure_zc(sbm_handle* h, size_t bytes) {
   // the next call simply completes)
   if (!h->zc_flag) {
     HIPCHK(h, hipHostMalloc((void**)&h->zc_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *h->zc_flag = 0u;
+    for (int k = 0; k < kZcChunks; k++) h->zc_flag[k] = 0u;
     h->zc_seq = 0u;
   }
   if (!h->zc_cnt) {
@@ -1137,32 +1144,47 @@ static int ensure_zc(sbm_handle* h, size_t bytes) {
   return SBM_OK;
 }
 
-// queue the copy kernel behind the call's kernels and wait for its flag; on return the maps are in h->zc_out
-static int maps_out_and_wait(sbm_handle* h, const int16_t* d_src, size_t count) {
-  const size_t bytes = count * sizeof(int16_t);
+// queue the copy kernel behind the call's kernels; the maps arrive in h->zc_out chunk by chunk and go to the caller (n dense maps
+// of npix1 pixels at disp[i]) as they arrive
+static int maps_out_to_caller(sbm_handle* h, const int16_t* d_src, int n, size_t npix1, int16_t* const* disp) {
+  const size_t count = (size_t)n * npix1, bytes = count * sizeof(int16_t);
   int st = ensure_zc(h, bytes);
   if (st != SBM_OK) return st;
   const size_t n16 = bytes / 16;
   const int ntail = (int)((bytes - n16 * 16) / 2);
   const unsigned seq = ++h->zc_seq == 0u ? ++h->zc_seq : h->zc_seq;   // (0 is "nothing yet")
-  const unsigned blocks = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (n16 + 511) / 512));
-  hipLaunchKernelGGL(maps_out_kernel, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(h->zc_out), n16,
-                     d_src + n16 * 8, h->zc_out + n16 * 8, ntail, h->zc_cnt, h->zc_flag, seq);
+  const int nch = (int)std::min<size_t>(kZcChunks, std::max<size_t>(1, bytes >> 16));        // chunks of at least 64 KB
+  const size_t per_chunk = (n16 + nch - 1) / nch;
+  const int bpc = (int)std::min<size_t>(256 / nch, std::max<size_t>(1, (per_chunk + 511) / 512));   // blocks per chunk
+  hipLaunchKernelGGL(maps_out_kernel, dim3(nch * bpc), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(h->zc_out), n16,
+                     per_chunk, bpc, d_src + n16 * 8, h->zc_out + n16 * 8, ntail, h->zc_cnt, h->zc_flag, seq);
   HIPCHK(h, hipGetLastError());
-  // Poll the flag: a short pure spin (a one-pair call ends within tens of microseconds of the launch), then spin with yields
-  // so that a loaded host or many engines driven from many threads do not burn a core each, and after 2 ms the runtime's own
-  // wait -- also the way out when the stream has failed and the flag will never be raised.
+  // Poll the chunk flags in order: a short pure spin (a one-pair call ends within tens of microseconds of the launch), then spin
+  // with yields so that a loaded host or many engines driven from many threads do not burn a core each, and after 2 ms the
+  // runtime's own wait -- also the way out when the stream has failed and the flags will never be raised.
   const auto t0 = std::chrono::steady_clock::now();
-  unsigned spins = 0;
-  while (__atomic_load_n(h->zc_flag, __ATOMIC_ACQUIRE) != seq) {
-    cpu_relax();
-    if ((++spins & 0xffu) == 0u) {
-      const auto dt = std::chrono::steady_clock::now() - t0;
-      if (dt > std::chrono::milliseconds(2)) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        break;
+  bool synced = false;
+  size_t done = 0;   // int16 elements already with the caller
+  for (int c = 0; c < nch; c++) {
+    unsigned spins = 0;
+    while (!synced && __atomic_load_n(h->zc_flag + c, __ATOMIC_ACQUIRE) != seq) {
+      cpu_relax();
+      if ((++spins & 0xffu) == 0u) {
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt > std::chrono::milliseconds(2)) {
+          HIPCHK(h, hipStreamSynchronize(h->stream));
+          synced = true;
+        } else if (dt > std::chrono::microseconds(150)) {
+          std::this_thread::yield();
+        }
       }
-      if (dt > std::chrono::microseconds(150)) std::this_thread::yield();
+    }
+    // elements [done, end) have landed: hand them to the maps they belong to
+    const size_t end = c == nch - 1 ? count : std::min(count, (size_t)(c + 1) * per_chunk * 8);
+    while (done < end) {
+      const size_t i = done / npix1, off = done - i * npix1, len = std::min(end - done, npix1 - off);
+      memcpy(disp[i] + off, h->zc_out + done, len * sizeof(int16_t));
+      done += len;
     }
   }
   return SBM_OK;
@@ -1266,10 +1288,8 @@ int sbm_compute_batch(sbm_handle* h, int n, const uint8_t* const* left, size_t l
     zero_copy = !(pe == hipSuccess && (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeDevice));
   }
   if (zero_copy) {
-    st = maps_out_and_wait(h, h->st_d, (size_t)n * npix1);
+    st = maps_out_to_caller(h, h->st_d, n, npix1, disp);
     if (st != SBM_OK) return st;
-    HP(3);
-    for (int i = 0; i < n; i++) memcpy(disp[i], h->zc_out + i * npix1, npix1 * 2);
     HP(4);
   } else if (out_dense) {
     for (int i = 0; i < n; i++)
