@@ -10,12 +10,16 @@
 // ndisp+hwsz+1+i) are derived in DESIGN.md (section "FPGA flavour").
 //
 // Mapping: a wavefront owns 64 consecutive HSAD columns (lane = column) and marches down the rows of one segment.
+//   rows    the wavefront's piece of a right row (63 + 4 NU bytes) is staged once by LDS-direct loads into a 4x-expanded
+//           layout (dword slot p = bytes p..p+3; round 6 -- the per-lane register copies of rounds 2-5 cost 40 VGPRs and a
+//           wavefront per SIMD), two areas: the entering and the leaving row, loaded a row ahead
 //   AD      one v_mqsad_pk_u16_u8 with a single-byte pattern = |R[t..t+3] - L| for 4 consecutive disparities
 //           (9 per row cover the 34 lanes of a phase); the leaving row is re-evaluated instead of stored
 //   HSAD    18 VGPRs of packed u16: v_pk_add_u16 + v_pk_min_u16(.., 1023) on entry, v_pk_sub_u16 clamp on exit
 //   SAD     inclusive prefix sum over the 64 lanes (4 DPP row shifts + 2 row broadcasts per register; 64 * 1023 still
 //           fits 16 bits), window sum = P[l + 2*hwsz] - P[l - 1] through LDS
-//   det     key minimum per quarter of the tournament, the top two rounds literally
+//   det     key minimum per quarter of the tournament, the top two rounds literally; with the uniqueness filter off and the
+//           whole range in one launch (the firmware's configuration) a plain first minimum, the fraction once per pixel (LEAN)
 // The 10-bit saturation makes HSAD history dependent, so row segments are only exact while nothing saturates: the
 // segmented launch stamps a per-pair word with the call's generation number when a column sum passes 1023 and a second,
 // one-segment launch (which exits immediately for unstamped pairs; not launched when wsz * 63 <= 1023) recomputes such
@@ -121,8 +125,15 @@ __device__ __forceinline__ u32 pk_max(u32 a, u32 b) {
 // through the record plane, once per 4 phases. The x-Sobel planes are read where they lie: range-checked buffer loads
 // return 0 for the few window bytes of the padding lanes that fall outside the batch, and rows/columns the RTL never
 // writes get the firmware's 0xFFFF from the same kernel.
-template <int NPH>
-__global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
+// LEAN: the whole disparity range in this launch and the uniqueness filter off (what the firmware programs: fpga.c:150-160 never
+// writes UniFiltCtrl) -- the second minimum of bm_calc_det.v / bm_calc_upd.v then feeds nothing: the search is a plain first
+// minimum, the merge across phases "strictly smaller wins", and the sub-pixel fraction (nine divider steps) is taken once per
+// pixel, for the final winner, from its two neighbour sums carried along.
+#ifndef SBM_FPGA_WPE2   // wavefronts per SIMD the register allocation of the two-phase kernel aims at (development builds compare)
+#define SBM_FPGA_WPE2 3
+#endif
+template <int NPH, bool LEAN>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPH == 1 ? 4 : (NPH == 2 ? SBM_FPGA_WPE2 : 1)))) fpga_bm_kernel(FpgaArgs a) {
   const int lane = threadIdx.x;
   const int pair = blockIdx.z;
   if (a.exact && a.flag[pair] != a.gen) return;
@@ -140,10 +151,22 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xl + pair * plane), 0, nrec, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xr + pair * plane), 0, nrec, 0x00020000);
   // window byte t of phase kk = R[x - 32 kk - 33 + t], t = 34 - j for lane j (disparity 32 kk + j - 1). The phases of
-  // this launch read one piece: bytes x - 32 (phase0 + NPH - 1) - 33 ... + 32 (NPH - 1) + 39, phase k at dword 8 (NPH-1-k)
+  // this launch read one piece per lane: bytes x - 32 (phase0 + NPH - 1) - 33 ... + 32 (NPH - 1) + 39, phase k at dword
+  // 8 (NPH-1-k). Adjacent lanes' pieces overlap in all but one byte, so the wavefront's piece -- 63 + 4 NU bytes from the
+  // first lane's start -- is staged ONCE, by LDS-direct loads into a 4x-expanded layout (dword slot p = bytes p .. p+3 of the
+  // piece: lane i of a load writes its 4 source bytes to slot i, a byte-granular source address is fine), and lane l reads
+  // dword j of its window from slot l + 4 j. Round 6: before, every lane held its own 4 NU bytes of two rows in registers
+  // (192 VGPRs = 2 wavefronts per SIMD at two phases; 243 register moves per row to rotate clamped pieces into place).
   constexpr int NU = 8 * (NPH - 1) + 10;
-  const int ubase = x - 32 * (a.phase0 + NPH - 1) - 33;   // (-1 for the first column of the last phase: reads as 0 in pair 0)
-  u32* const xrow = fpga_lds;                     // [FP_NR][FP_XS]
+  constexpr int NS = 64 + 4 * (NU - 1);            // slots a wavefront reads
+  constexpr int NLD = (NS + 63) / 64;              // LDS-direct loads per staged row
+  constexpr int SROW = 64 * NLD;                   // dword slots of one staged-row area
+  const int cb = blockIdx.x * NV;                  // HSAD column of lane 0
+  const int pbase = a.nd + cb - 32 * (a.phase0 + NPH - 1) - 33;   // piece start within a row (-1 for strip 0 of the launch with the last phase)
+  u32* const xrow = fpga_lds;                      // [FP_NR][FP_XS]
+  u32* const stg0 = fpga_lds + FP_NR * FP_XS;      // staged rows: entering / leaving
+  u32* const stg1 = stg0 + SROW;
+  typedef __attribute__((address_space(3))) void* lds_vptr;
 
   u32 V[NPH][FP_NR];
 #pragma unroll
@@ -152,67 +175,67 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
     for (int r = 0; r < FP_NR; r++) V[k][r] = 0u;
   u32 satmax = 0u;
 
-  struct Row { u32 u[NU]; u32 l; int delta; };   // delta: wanted byte t = loaded byte t + delta (0 but for the few clamped lanes)
-  auto fetch = [&](int y) {
-    Row g;
-    // Loads never leave the frame's descriptor: a range check that fails zeroes the WHOLE 16- / 8-byte load, and two kinds
-    // of pieces would straddle -- HSAD column 0 of the launch that holds the last phase starts one byte in front of its row
-    // (offset -1 in row 0 of a frame), the last columns of the last row of the LAST frame end a few bytes behind the
-    // batch (only bytes of padding lanes lie outside, but they share loads with real ones). So the piece is loaded from a
-    // start clamped into the descriptor and, in the few wavefronts where a lane was clamped (wave-uniform test), rotated
-    // back into place byte-wise; what falls outside reads as 0, like the zero-padded copies of rounds 1-2.
-    const int vo = y * a.W + ubase;
-    const int vs = min(max(vo, 0), (int)nrec - 4 * NU);
+  // stage row y into `buf`; returns this lane's left byte (a register load that lands with the row)
+  auto stage = [&](const int y, u32* const buf) -> u32 {
+    const int po = y * a.W + pbase;                // piece start as a byte offset into the pair's plane (uniform)
 #pragma unroll
-    for (int i = 0; i + 4 <= NU; i += 4) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vs + 4 * i, 0, 0);
-      g.u[i] = v.x; g.u[i + 1] = v.y; g.u[i + 2] = v.z; g.u[i + 3] = v.w;
-    }
-    {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vs + 4 * (NU - 2), 0, 0);
-      g.u[NU - 2] = v.x; g.u[NU - 1] = v.y;
-    }
-    g.l = (u32)__builtin_amdgcn_raw_buffer_load_b8(rs_l, y * a.W + x, 0, 0);
-    g.delta = vo - vs;                             // -1 <= delta <= 7
-    return g;
+    for (int it = 0; it < NLD; it++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vptr)(buf + 64 * it), 4, po + 64 * it + lane, 0, 0, 0);
+    return (u32)__builtin_amdgcn_raw_buffer_load_b8(rs_l, y * a.W + x, 0, 0);
   };
-  // rotate a clamped piece back into place, where it is consumed (the loads have landed by then: done right behind the
-  // loads, the branch join made every row wait for its own loads and cost 7 %)
-  auto settle = [&](Row& g) {
-    if (__builtin_amdgcn_ballot_w64(g.delta != 0) != 0ull) {
-      const int dq = g.delta >> 2;                 // -1, 0 or 1 (arithmetic shift)
-      const u32 sh = (u32)g.delta & 3u;
-      u32 r[NU];
+  // everything in flight has landed. The hardware zeroes a WHOLE dword whose range check fails, and two kinds of slots
+  // straddle the descriptor: slot 0 of the piece that starts one byte in front of its plane (row 0, strip 0, the launch that
+  // holds the last phase -- only a padding lane's byte lies outside, but it shares the dword with real ones) and the slots
+  // over the last three bytes of the batch (last rows of the LAST frame). Both are rebuilt from a neighbour slot that lies
+  // inside (wave-uniform, rare branches).
+  auto landed = [&](const int y, u32* const buf) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int po = y * a.W + pbase;
+    if (po < 0) {                                   // (po == -1) slot 0 = bytes -1 .. 2: byte -1 reads as 0, the others sit in slot 1
+      if (lane == 0) buf[0] = buf[1] << 8;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if ((unsigned)(po + SROW + 3) > nrec) {         // slots p with p + 3 >= nrec > p: from the last dword that lies inside
+      const int s4 = (int)nrec - 4 - po;            // its slot
 #pragma unroll
-      for (int i = 0; i < NU; i++) {
-        const u32 m1 = i >= 1 ? g.u[i - 1] : 0u, p0 = g.u[i], p1 = i + 1 < NU ? g.u[i + 1] : 0u, p2 = i + 2 < NU ? g.u[i + 2] : 0u;
-        const u32 lo = dq < 0 ? m1 : (dq == 0 ? p0 : p1), hi = dq < 0 ? p0 : (dq == 0 ? p1 : p2);
-        r[i] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      for (int it = 0; it < NLD; it++) {
+        const int p = 64 * it + lane, over = p - s4;   // 1 .. 3: bytes that fall outside
+        if (s4 >= 0 && over >= 1 && over <= 3) buf[p] = buf[s4] >> (8 * over);
       }
-#pragma unroll
-      for (int i = 0; i < NU; i++) g.u[i] = r[i];
-      g.delta = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   };
-  // |R[t] - L| for the 36 window bytes of one row and phase, packed like V
-  auto row_ad = [&](const Row& g, const int k, u32 (&ad)[FP_NR]) {
-    const u32 l = (g.l & 63u) + 1u;               // +1: a zero pattern byte would be masked by the instruction
+  auto reads_done = [] {    // every LDS read of this wavefront has returned: an area may be overwritten
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // |R[t] - L| for the 36 window bytes of one staged row and phase, packed like V
+  auto row_ad = [&](const u32* const buf, const u32 lb, const int k, u32 (&ad)[FP_NR]) {
+    // 6 significant bits (bm_calc_sad.v:375,380); bit 6 set on both sides cancels in the difference and keeps the pattern byte
+    // from being zero (a zero pattern byte is masked by the instruction)
+    const u32 l = (lb & 63u) | 64u;
+    const u32* const w = buf + lane + 32 * (NPH - 1 - k);
+    u32 u[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) u[q] = w[4 * q];
 #pragma unroll
     for (int q = 0; q < 9; q++) {
-      // 6 significant bits (bm_calc_sad.v:375,380); the +1 bias cancels in the difference
-      const u32 wq = (g.u[8 * (NPH - 1 - k) + q] & 0x3f3f3f3fu) + 0x01010101u;
-      const u64 win = ((u64)g.u[8 * (NPH - 1 - k) + q + 1] << 32) | wq;   // only bytes 0..3 meet a non-masked pattern byte
+      const u32 wq = (u[q] & 0x3f3f3f3fu) | 0x40404040u;
+      const u64 win = ((u64)u[q + 1] << 32) | wq;   // only bytes 0..3 meet a non-masked pattern byte
       const u64 m = __builtin_amdgcn_mqsad_pk_u16_u8(win, l, 0ull);
       ad[2 * q] = (u32)m;
       ad[2 * q + 1] = (u32)(m >> 32);
     }
   };
-  auto add_row = [&](Row& g) {                    // bm_calc_sad.v:450-457: + |.|, upper limit 1023
-    settle(g);
+  auto add_row = [&](const u32* const buf, const u32 lb) {   // bm_calc_sad.v:450-457: + |.|, upper limit 1023
 #pragma unroll
     for (int k = 0; k < NPH; k++) {
       u32 ad[FP_NR];
-      row_ad(g, k, ad);
+      row_ad(buf, lb, k, ad);
 #pragma unroll
       for (int r = 0; r < FP_NR; r++) {
         const u32 sum = pk_add(V[k][r], ad[r]);
@@ -221,24 +244,28 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       }
     }
   };
-  auto sub_row = [&](Row& g) {                    // bm_calc_sad.v:459-462: - |.|, lower limit 0
-    settle(g);
+  auto sub_row = [&](const u32* const buf, const u32 lb) {   // bm_calc_sad.v:459-462: - |.|, lower limit 0
 #pragma unroll
     for (int k = 0; k < NPH; k++) {
       u32 ad[FP_NR];
-      row_ad(g, k, ad);
+      row_ad(buf, lb, k, ad);
 #pragma unroll
       for (int r = 0; r < FP_NR; r++) V[k][r] = pk_subs(V[k][r], ad[r]);
     }
   };
 
-  {
-    Row g = fetch(r0);
-    for (int y = r0; y < r0 + a.wsz - 1; y++) {   // rows of the first window but the last
-      Row n = fetch(y + 1);
-      add_row(g);
-      g = n;
-    }
+  // rows of the first window but the last, alternating between the two areas (the next one arrives while one is consumed);
+  // the row staged last -- into whichever area is then due -- is the first output row's entering row
+  u32 le = stage(r0, stg0), ll = 0u;
+  u32* be = stg0;            // area of the row that enters next
+  u32* bl = stg1;
+  for (int y = r0; y < r0 + a.wsz - 1; y++) {
+    landed(y, be);
+    const u32 ln = stage(y + 1, bl);
+    add_row(be, le);
+    reads_done();
+    le = ln;
+    u32* const t = be; be = bl; bl = t;
   }
 
   if (lane == 0) {
@@ -267,11 +294,14 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       for (int yy = a.hwsz + a.sad_hgt; yy < a.H; yy++) fill_row(yy);
   }
 
-  Row ge = fetch(r0 + a.wsz - 1);
   for (int r = r0; r < r1; r++) {
-    add_row(ge);
-    Row gl = fetch(r);                             // the leaving row, consumed at the end of the iteration
-    if (r + 1 < r1) ge = fetch(r + a.wsz);
+    // `be` holds row r + wsz - 1 (entering); it is consumed here, then both areas take the rows this iteration's end and the
+    // next one's start need -- the leaving row r and the next entering row -- which land under the phases below
+    landed(r + a.wsz - 1, be);
+    add_row(be, le);
+    reads_done();
+    ll = stage(r, bl);
+    if (r + 1 < r1) le = stage(r + a.wsz, be);
     u32 min1 = 0, min2 = 0, disp1 = 0, disp2 = 0, frac = 0;
     uint2* rp = a.rec + ((size_t)pair * a.sad_hgt + r) * a.sad_wdt + i;
     if (!a.first && sample) {                      // a range of more than NPH phases: the record of the earlier launches
@@ -306,6 +336,34 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       for (int q = 0; q < FP_NR; q++) S[q] = xrow[q * FP_XS + 1 + lxo + 2 * a.hwsz] - xrow[q * FP_XS + lxo];
       __builtin_amdgcn_s_setprio(0);
 
+      // neighbours of a winner lane jw = idx + 1: lanes jw - 1 and jw + 1, looked up in the prefix rows
+      auto sad_of_lane = [&](int j) -> u32 {
+        const int q = (34 - j) >> 1, hi = (34 - j) & 1;   // lane 34-2q is the low half
+        const u32 pa = xrow[q * FP_XS + 1 + lxo + 2 * a.hwsz], pb = xrow[q * FP_XS + lxo];
+        const u32 d = pa - pb;
+        return hi ? (d >> 16) : (d & 0xffffu);
+      };
+      if constexpr (LEAN) {
+        if (sample) {
+          // first minimum over the 32 lanes by keys (value << 16 | idx, idx = lane - 1): reg q holds lane 34-2q (low half,
+          // idx 33-2q) and lane 33-2q (high half, idx 32-2q), q = 1 .. 16
+          u32 b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+          for (int q = 1; q <= 16; q++) {
+            const u32 klo = (S[q] << 16) | (u32)(33 - 2 * q), khi = (S[q] & 0xffff0000u) | (u32)(32 - 2 * q);
+            b[q & 3] = min(b[q & 3], min(klo, khi));
+          }
+          const u32 win = min(min(b[0], b[1]), min(b[2], b[3]));
+          const int i1 = (int)(win & 0xffffu);
+          const u32 dmin1 = win >> 16;
+          if (k == 0 || dmin1 < min1) {                // bm_calc_upd.v:125-209 reduced to its min1 / disp1 columns
+            min1 = dmin1;
+            disp1 = (u32)((((a.phase0 + k) & 7) << 5) | i1);
+            min2 = sad_of_lane(i1);                    // (the dead second-minimum registers carry the winner's neighbour sums)
+            disp2 = sad_of_lane(i1 + 2);
+          }
+        }
+      } else
       if (sample) {
         // ---- bm_calc_det.v: first minimum of every quarter by keys (value << 16 | idx, idx = lane - 1); reg q holds
         // lane 34-2q (low half, idx 33-2q) and lane 33-2q (high half, idx 32-2q); quarter m = regs 16-4m-3 .. 16-4m
@@ -331,13 +389,6 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
         const u32 dmin1 = win >> 16, dmin2 = m2k >> 16;
         const int k32 = ((a.phase0 + k) & 7) << 5;
         const u32 ddisp1 = (u32)(k32 | i1), ddisp2 = (u32)(k32 | (int)(m2k & 0xffffu));
-        // neighbours of the winner lane jw = i1 + 1: lanes jw - 1 and jw + 1, looked up in the prefix rows
-        auto sad_of_lane = [&](int j) -> u32 {
-          const int q = (34 - j) >> 1, hi = (34 - j) & 1;   // lane 34-2q is the low half
-          const u32 pa = xrow[q * FP_XS + 1 + lxo + 2 * a.hwsz], pb = xrow[q * FP_XS + lxo];
-          const u32 d = pa - pb;
-          return hi ? (d >> 16) : (d & 0xffffu);
-        };
         const u32 dl = sad_of_lane(i1), dr = sad_of_lane(i1 + 2);
         const u32 frac_new = rtl_frac(dmin1, dl, dr);
 
@@ -366,7 +417,9 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
     }
     int16_t* orow = dpair + (size_t)(a.hwsz + r) * a.W;
     if (sample) {
-      if (!a.last) {
+      if constexpr (LEAN) {
+        orow[col_s + i] = (int16_t)rtl_pack(disp1, rtl_frac(min1, min2, disp2));
+      } else if (!a.last) {
         *rp = make_uint2(min1 | (min2 << 16), disp1 | (disp2 << 8) | (frac << 16));
       } else {
         u32 od = disp1, of = frac;
@@ -383,7 +436,11 @@ __global__ void __launch_bounds__(64) fpga_bm_kernel(FpgaArgs a) {
       if (blockIdx.x == gridDim.x - 1)
         for (int xx = col_s + a.sad_wdt + lane; xx < a.W; xx += 64) orow[xx] = (int16_t)-1;
     }
-    if (r + 1 < r1) sub_row(gl);
+    if (r + 1 < r1) {
+      landed(r, bl);          // (covers the next entering row in `be` as well; its own fix-ups run at the top of the next iteration)
+      sub_row(bl, ll);
+      reads_done();
+    }
   }
   if (a.track_sat && !a.exact && col_ok && (satmax & 0x04000400u)) atomicMax(a.flag + pair, a.gen);
 }
@@ -406,7 +463,8 @@ hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, void* rec, int* 
   // segments: enough wavefronts for the chip, each paying wsz-1 priming rows
   int nseg = 1;
   while ((long)strips * nseg * n < 4096 && a.sad_hgt / (nseg + 1) >= 2 * a.wsz) nseg++;
-  const size_t lds = (size_t)FP_NR * FP_XS * sizeof(u32);
+  // prefix rows + the two staged-row areas of the widest launch (4 phases: 64 + 4 * 33 = 196 slots -> 4 loads of 64)
+  const size_t lds = (size_t)(FP_NR * FP_XS + 2 * 256) * sizeof(u32);
   const int nph = nphase >= 4 ? 4 : nphase;        // phases per launch: up to 4 live in one wavefront's registers
   for (int pass = 0; pass < 2; pass++) {
     // pass 0: segmented (exact unless a column sum saturates); pass 1: flagged pairs only, one segment top to bottom
@@ -419,9 +477,17 @@ hipError_t launch_fpga_bm(const uint8_t* xl, const uint8_t* xr, void* rec, int* 
       // the remaining phases in groups of 4, 2 or 1 (3 phases = 2 + 1, 6 = 4 + 2, ...)
       const int left = nphase - k, grp = left >= 4 && nph == 4 ? 4 : (left >= 2 ? 2 : 1);
       a.phase0 = k; a.first = k == 0; a.last = k + grp == nphase;
-      if (grp == 4) hipLaunchKernelGGL(fpga_bm_kernel<4>, grid, dim3(64), lds, s, a);
-      else if (grp == 2) hipLaunchKernelGGL(fpga_bm_kernel<2>, grid, dim3(64), lds, s, a);
-      else hipLaunchKernelGGL(fpga_bm_kernel<1>, grid, dim3(64), lds, s, a);
+      const bool lean = a.first && a.last && !a.uni_enb;   // the whole range in one launch, no uniqueness filter
+      if (grp == 4) {
+        if (lean) hipLaunchKernelGGL((fpga_bm_kernel<4, true>), grid, dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((fpga_bm_kernel<4, false>), grid, dim3(64), lds, s, a);
+      } else if (grp == 2) {
+        if (lean) hipLaunchKernelGGL((fpga_bm_kernel<2, true>), grid, dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((fpga_bm_kernel<2, false>), grid, dim3(64), lds, s, a);
+      } else {
+        if (lean) hipLaunchKernelGGL((fpga_bm_kernel<1, true>), grid, dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((fpga_bm_kernel<1, false>), grid, dim3(64), lds, s, a);
+      }
       k += grp;
     }
   }
