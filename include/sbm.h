@@ -22,24 +22,31 @@
  * There is NO CPU backend behind this ABI: if no HIP device is usable sbm_create() fails with
  * SBM_ERR_NO_DEVICE. The CPU restatement used by the tests lives in oracle/ and is never linked here.
  *
- * Exactness. Every parameter set cv::StereoBM accepts is computed (block sizes 5..255, any multiple of 16 disparities, any
- * minDisparity / ROI); sets inside the fast envelope -- odd block size 5..31, numDisparities <= 512, blockSize^2 * 2 *
- * preFilterCap <= 65534 -- run the hand-tuned kernels (4 T pixel-disparities/s), everything else a sliding-sum kernel with 32-bit
- * sums (0.15-0.5 T, same results; up to 2048 disparities, beyond that a per-column kernel ~10x slower again).
+ * Exactness. Every parameter set cv::StereoBM accepts is computed (block sizes 5..255, any minDisparity / ROI, any multiple of 16
+ * disparities up to the limits below); sets inside the fast envelope -- odd block size 5..31, numDisparities <= 512, blockSize^2
+ * * 2 * preFilterCap <= 65534 -- run the hand-tuned kernels (4 T pixel-disparities/s), everything else a sliding-sum kernel with
+ * 32-bit sums (0.15-0.5 T, same results; up to 2048 disparities, beyond that a per-column kernel ~10x slower again).
  * Bit-exactness against cv::StereoBM is CLAIMED for blockSize^2 * 2 * preFilterCap <= 32767 only (the reference's 21 x 21
  * at cap 31 is 27 342): OpenCV keeps its block-matching cost plane as `short`, so beyond that bound its left-right check
  * would see a wrapped cost where this engine (and its oracle) keep the true one.
  *
- * Environment. The library reads these eight variables (nothing else); an integrator never needs to set any of them:
+ * Limits (SBM_ERR_UNSUPPORTED beyond them; cv::StereoBM itself has none of these): numDisparities <= 4096, at most 32 767 pairs
+ * per call, image height <= 65 535. The speckle filter's band walk serves images up to 2^27 pixels and 65 535 columns, larger
+ * ones its row-walking kernels (same results).
+ *
+ * The hand-tuned kernels accumulate in place with v_mqsad_pk_u16_u8 (vdst == src2), which the hardware does right and the
+ * compiler's register model forbids; a device self-test (once per device and process, on the first handle's stream: pseudo-random
+ * operands, single instructions and dependent chains, at 1 / 4 / 8 wavefronts per SIMD) guards it. What the self-test does NOT
+ * cover is a device that miscomputes only in instruction mixes it does not generate. If it fails, or with SBM_FAST_INPLACE=0, the
+ * two-accumulator build runs instead: same results, 64-disparity layouts (~1.3x slower at 128 disparities), block sizes up to 27
+ * and up to 256 disparities -- block sizes 29 / 31 and 257..512 disparities then fall to the sliding-sum kernel (8-25x slower; the
+ * kernel name, sbm_last_kernel_name(), then reads "sad_wide_kernel [in-place accumulate unavailable]").
+ *
+ * Environment. The library reads these seven variables (nothing else); an integrator never needs to set any of them:
  *   variable            default  read      who sets it, and what for
  *   SBM_FAST_INPLACE    1        once      0 = run the two-accumulator build of the SAD kernel (the fallback that is taken
  *                                          automatically when the device self-test of the in-place v_mqsad accumulate
  *                                          fails); set by the GPU tests to check that fallback
- *   SBM_FAST_MODE       2        once      layout of the interior SAD kernel from 65 to 256 disparities: 2 = one 128-disparity
- *                                          wavefront up to 128, two of them beyond (three 64-disparity ones at exactly 192);
- *                                          1 = one 128-disparity wavefront up to 128, 64-disparity cooperating wavefronts
- *                                          beyond; 0 = 64 disparities per wavefront everywhere (round-2 layout); GPU tests /
- *                                          A-B measurements
  *   SBM_FAST_PFSHIFT    2        once      0 = unscaled prefiltered planes (plain winner search), 1 = at most one tag bit;
  *                                          GPU tests
  *   SBM_FAST_CS3        1        per call  0 = plain column strips only (no column-stride-3 strips); GPU tests
@@ -54,8 +61,9 @@
  *   SBM_WIDE            1        per call  0 = configurations outside the fast envelope run the per-column kernel
  *                                          (sbm_sad_generic.hip) instead of the sliding-sum one (sbm_sad_wide.hip); GPU tests
  * Tuning knobs of the measurement scripts (SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
- * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*) exist only in development builds (-DSBM_DEV,
- * tools/exp/r04_devlib.sh); this library ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this
+ * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*; the interior kernel's are listed in
+ * u96-slam_amd/csrc/sbm_sad_fast_dev.h) exist only in development builds (-DSBM_DEV, tools/exp/r05_devlib.sh); this library
+ * ignores them. The Python mirror adds SBM_LIB_AB (file name of another build of this
  * library inside u96-slam_amd/lib/, A-B measurements only); bench.py reads SBM_BENCH_BACKEND / SBM_BENCH_FEED /
  * SBM_BENCH_SG_FAULT (tests of its multi-process control flow).
  */

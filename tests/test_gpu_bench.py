@@ -160,29 +160,27 @@ def test_async_dense_feed_matches_the_synchronous_call():
     bm.wait_host()           # nothing outstanding: returns at once
 
 
-@pytest.mark.parametrize("env,kernel", [
-    ({"SBM_FAST_INPLACE": "0"}, "sad_fast_pp_kernel<64,2,5,3,false,true> pfshift=2"),     # two-accumulator fallback build (round-2 layout, masked-count kernels only)
-    ({"SBM_FAST_MODE": "0"}, "sad_fast_kernel<64,2,5,3,true,true> pfshift=2"),             # in place, two cooperating wavefronts
-    ({"SBM_FAST_PFSHIFT": "0"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),         # unscaled planes, plain key search
-    ({"SBM_FAST_PFSHIFT": "1"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),         # w 15 kernels hold the two-bit variant only
-    ({"SBM_FAST_CS3": "0"}, "sad_fast_kernel<128,1,5,3,true,true> pfshift=2"),             # plain strips only (no column stride 3)
+@pytest.mark.parametrize("env,args,kernel", [
+    ({"SBM_FAST_INPLACE": "0"}, ["--pairs", "8"], "sad_fast_pp_kernel<64,2,5,3,false,true> pfshift=2"),   # two-accumulator fallback build (64-disparity layouts, masked-count kernels only)
+    ({}, ["--pairs", "1"], "sad_fast_kernel<64,2,5,3,true,true> pfshift=2"),                              # one pair per call: the disparities split over two cooperating wavefronts
+    ({"SBM_FAST_PFSHIFT": "0"}, ["--pairs", "8"], "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),      # unscaled planes, plain key search
+    ({"SBM_FAST_PFSHIFT": "1"}, ["--pairs", "8"], "sad_fast_kernel<128,1,5,3,true,true> pfshift=0"),      # w 15 kernels hold the two-bit variant only
+    ({"SBM_FAST_CS3": "0"}, ["--pairs", "8"], "sad_fast_kernel<128,1,5,3,true,true> pfshift=2"),          # plain strips only (no column stride 3)
 ])
-def test_engine_variants_are_bit_exact(env, kernel):
+def test_engine_variants_are_bit_exact(env, args, kernel):
     """Every selectable variant of the interior kernel against the oracle on the bench workload (the engine reads these
     switches once per process, hence the subprocess): the fallback that runs when the device self-test of the in-place
     v_mqsad accumulate fails must be as exact as the default."""
-    j = _run(["--steps", "2", "--warmup", "1", "--pairs", "8", "--cpu-sample", "8", "--check"], env=env)
+    j = _run(["--steps", "2", "--warmup", "1", "--cpu-sample", "8", "--check"] + args, env=env)
     assert j["roofline"]["kernel"] == kernel
     assert j["cpu_baseline"]["bit_exact_vs_gpu"] is True
 
 
-@pytest.mark.parametrize("env,kernel", [
-    ({}, "sad_fast_kernel<128,2,7,3,true,true> pfshift=1"),                      # two 128-disparity wavefronts, LDS-direct staging
-    ({"SBM_FAST_MODE": "1"}, "sad_fast_kernel<64,4,7,3,false,true> pfshift=1"),   # four 64-disparity wavefronts (masked-count kernel: <64,4> has no exact one)
-])
-def test_256_disparities_both_layouts_are_bit_exact(env, kernel):
-    j = _run(["--steps", "2", "--warmup", "1", "--pairs", "4", "--cpu-sample", "2", "--check", "--workload", "fhd", "--prewarm-s", "0"], env=env)
-    assert j["roofline"]["kernel"] == kernel and j["cpu_baseline"]["bit_exact_vs_gpu"] is True
+def test_256_disparities_two_cooperating_wavefronts_bit_exact():
+    """BASELINE configs[2]'s layout: two 128-disparity wavefronts, LDS-direct staging (the four 64-disparity wavefronts that
+    small launches take instead: tests/test_gpu_fallback.py::test_one_small_pair_at_256_disparities)."""
+    j = _run(["--steps", "2", "--warmup", "1", "--pairs", "4", "--cpu-sample", "1", "--check", "--workload", "fhd", "--prewarm-s", "0"])
+    assert j["roofline"]["kernel"] == "sad_fast_kernel<128,2,7,3,true,true> pfshift=1" and j["cpu_baseline"]["bit_exact_vs_gpu"] is True
 
 
 def test_reference_window_uses_one_tag_bit():

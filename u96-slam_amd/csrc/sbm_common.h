@@ -11,11 +11,12 @@ namespace sbm {
 
 // Environment switches of the library -- the complete list, documented for integrators in include/sbm.h ("Environment").
 //   env_switch(): read in every build. They select a tested fallback or a code path that the GPU tests compare with the
-//                 default one: SBM_FAST_INPLACE, SBM_FAST_MODE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS,
-//                 SBM_SPECKLE_BAND, SBM_HOST_ZEROCOPY, SBM_WIDE.
+//                 default one: SBM_FAST_INPLACE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS, SBM_SPECKLE_BAND,
+//                 SBM_HOST_ZEROCOPY, SBM_WIDE.
 //   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_NSEG, SBM_FAST_TAPER,
 //                 SBM_FAST_UNIQ_PLAIN, SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*): compiled in
-//                 only with -DSBM_DEV (the development library of tools/exp/r04_devlib.sh); the product ignores them.
+//                 only with -DSBM_DEV (the development library of tools/exp/r05_devlib.sh; sbm_sad_fast_dev.h lists the interior
+//                 kernel's); the product ignores them.
 inline int env_switch(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -72,8 +73,8 @@ bool sad_wide_supported(const Geom& g);
 hipError_t launch_sad_wide(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* disp, int32_t* cost, const Geom& g, int xa, int xb,
                            hipStream_t s);
 
-// Fast path (interior columns, block size multiple of 3 up to 21, 16-bit sums). Returns hipErrorNotSupported
-// when the configuration is outside its envelope; *xa,*xb receive the column range it covered.
+// Fast path (interior columns, odd block sizes 5..31, up to 512 disparities, 16-bit sums: sad_fast_supported()). Outside its
+// envelope the launch does nothing and returns hipSuccess; *xa,*xb receive the column range it covered.
 // name of the SAD kernel instantiation of the calling thread's last launch (template tuple; sbm_last_kernel_name())
 extern thread_local char g_sad_kernel_name[96];
 bool sad_fast_supported(const Geom& g);

@@ -1,5 +1,5 @@
 // sbm_sad_border_wave.h -- the w/2 clamped border columns of each side, as extra wavefronts of the interior SAD launch.
-// Included by sbm_sad_fast.hip (inside namespace sbm, after FastArgs).  gfx950 only.
+// Included by sbm_sad_fast_core.h (inside namespace sbm, after FastArgs).  gfx950 only.
 //
 // cv::StereoBM computes these columns with CLAMPED windows, lets them take part in
 // validateDisparity and only then overwrites them with FILTERED, so they must be bit-exact whenever the LR check is on
@@ -40,13 +40,6 @@
 //               <= the uniqueness threshold (sum-butterfly, several outputs per register).  One lane per (job, output)
 //               finishes: texture, uniqueness verdict, sub-pixel, stores.
 #pragma once
-
-#ifdef SBM_DEV_PROF   // profiling builds (they run several times slower): shader-clock cycles per phase of the border row loop, summed over all border wavefronts
-__device__ unsigned long long g_bw_prof[8];
-#define BW_T(i) do { const unsigned long long t_ = clock64(); if (lane == 0) atomicAdd(&g_bw_prof[i], t_ - bw_t); bw_t = clock64(); } while (0)
-#else
-#define BW_T(i) do { } while (0)
-#endif
 
 template <int GL>
 __device__ __forceinline__ u32 bw_bfly_min(u32 b) {
@@ -297,22 +290,16 @@ __device__ __forceinline__ void sad_border_wave_body(const FastArgs& a, unsigned
     if (fcost) fcost += a.W;
   };
 
-#ifdef SBM_DEV_PROF
-  unsigned long long bw_t = clock64();
-#endif
   for (int y = ys; y < ye; y++) {
     landed();                    // area 0: entering row y+W2; area 1 (y > ys): leaving row y-W2-1
-    BW_T(0);
     phase(0, +1);
     if (y > ys) phase(1, -1);    // S = window rows y-W2 .. y+W2
-    BW_T(1);
     if (y > ys) flush();         // row y-1
     if (y + 1 < ye) {            // next iteration's rows arrive under the winner search below
       landed_lds();              // (every read of the two areas has returned)
       stage(y + 1 + W2, 0);
       stage(y - W2, 1);
     }
-    BW_T(2);
 #pragma unroll
     for (int k = 0; k < NLL; k++)
       if (lane + 64 * k < JW * NVC) Tc[lane + 64 * k] = Ct[k];
@@ -366,7 +353,6 @@ __device__ __forceinline__ void sad_border_wave_body(const FastArgs& a, unsigned
       for (int j = 0; j < W2; j++) reinterpret_cast<u32*>(epw + 2 * j)[2] = (pk[j / FPR] >> (FB * (j % FPR))) & ((1u << FB) - 1u);
     }
     lds_sync();
-    BW_T(3);
     // ---- one lane per (job, output column) finishes -------------------------------------------------------------------
     if (fvalid) {
       const uint4 e = Ep[lane];
@@ -403,10 +389,6 @@ __device__ __forceinline__ void sad_border_wave_body(const FastArgs& a, unsigned
       cost_prev = cst;
     }
     lds_sync();   // Ep / Tc are rewritten by the next iteration
-    BW_T(4);
-#ifdef SBM_DEV_PROF
-    if (lane == 0) atomicAdd(&g_bw_prof[7], 1ull);
-#endif
   }
   flush();        // the segment's last row
 }
