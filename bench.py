@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--prewarm-s", type=float, default=0.3,
                     help="untimed steps for at least this many seconds BEFORE the --warmup steps (clock ramp; disclosed as prewarm_s)")
     ap.add_argument("--no-sg", action="store_true", help="N>1: skip the scatter/gather leg")
+    ap.add_argument("--no-multi", action="store_true", help="N>1: skip the one-process C++ leg (sbm_compute_batch_multi over the visible devices)")
     ap.add_argument("--sg-timeout", type=float, default=180.0, help="N>1: wall-clock limit of the scatter/gather child processes")
     ap.add_argument("--sg-child", action="store_true", help=argparse.SUPPRESS)   # internal: this process IS a scatter/gather child
     args = ap.parse_args()
@@ -463,6 +464,44 @@ def main():
             dist.barrier()
             sg = run_sg_child(rank, int(os.environ.get("LOCAL_RANK", "0")), world, port[0], sys.argv[1:], args.sg_timeout)
 
+    # ---- the reference's own shape of "several GPUs": ONE process, one host thread, one engine per visible device and the whole
+    # global batch in one call (sbm_compute_batch_multi, INTEGRATION.md "Several GPUs from one C++ process"). Rank 0 runs it
+    # while the other ranks wait at a barrier; PCIe is inside (pinned host batch), so this is a host-feed rate, never `value`.
+    multi = None
+    if dist is not None and not scatter and not host_feed and not args.no_multi and not args.sg_child:
+        sync_all()
+        if rank == 0:
+            try:
+                ndev = torch.cuda.device_count()
+                n_glob = max(ndev, min(world * B, int(1.5e9 // (4 * W * H))))      # at most ~1.5 GB of pinned host memory
+                engines = []
+                for k in range(ndev):
+                    e = pkg.StereoBM.create(nd, wsz, device=k)
+                    e.setPreFilterCap(31); e.setMinDisparity(0); e.setTextureThreshold(10); e.setUniquenessRatio(10)
+                    if post:
+                        e.setSpeckleWindowSize(50); e.setSpeckleRange(32); e.setDisp12MaxDiff(1)
+                    engines.append(e)
+                mreps = (n_glob + uniq - 1) // uniq
+                mL = torch.from_numpy(np.concatenate([Lh[:uniq]] * mreps)[:n_glob]).pin_memory()
+                mR = torch.from_numpy(np.concatenate([Rh[:uniq]] * mreps)[:n_glob]).pin_memory()
+                mD = torch.empty((n_glob, H, W), dtype=torch.int16).pin_memory()
+                pkg.compute_multi(engines, mL.numpy(), mR.numpy(), mD.numpy())       # warm: scratch, staging sets, streams
+                nrep = max(2, min(args.steps, 5))
+                t1 = time.perf_counter()
+                for _ in range(nrep):
+                    pkg.compute_multi(engines, mL.numpy(), mR.numpy(), mD.numpy())
+                mms = (time.perf_counter() - t1) / nrep * 1e3
+                same = bool(torch.equal(mD[:min(B, n_glob)], dD[:min(B, n_glob)].cpu()))   # block 0 = this rank's resident shard
+                multi = {"api": "sbm_compute_batch_multi", "devices": ndev, "pairs_per_call": n_glob, "ms_per_call": round(mms, 4),
+                         "value": round(n_glob * W * H * nd / (mms * 1e-3) / 1e6, 2), "unit": "Mpix-disparities/s",
+                         "equals_resident_shard": same,
+                         "note": "one process, one host thread, one engine per visible device, contiguous pair blocks; pinned host "
+                                 "batch, H2D + compute + D2H per device inside the call (PCIe-inclusive: not comparable with value)"}
+                del engines
+            except Exception as ex:      # this leg must never cost the line
+                multi = {"error": f"{type(ex).__name__}: {ex}"}
+        sync_all()
+
     # ---- host feed: the three legs on their own (resident compute, H2D of the inputs, D2H of the maps) -> how much of the
     # shorter legs the three-stream pipeline hides: overlap_frac = 1 when a step costs only its slowest leg, 0 when the sum
     feed_legs = None
@@ -668,6 +707,8 @@ def main():
             out["rccl"] = rccl
         if sg is not None:
             out["scatter_gather"] = sg
+        if multi is not None:
+            out["multi_cxx"] = multi
         if host_feed:
             nbytes_in, nbytes_out = 2.0 * B * W * H, 2.0 * B * W * H
             out["host_feed"] = {"memory": "pinned (torch pin_memory = hipHostMalloc)", "h2d_GBps": round(nbytes_in / (ms_per_step * 1e-3) / 1e9, 2),

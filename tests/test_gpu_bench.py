@@ -52,6 +52,7 @@ def test_two_ranks_self_launched(extra):
     # the default line carries the multi-GPU evidence without any flag: rank identity + the chunked scatter/gather
     assert j["rccl"]["ranks_seen"] == 2 and j["rccl"]["distinct_devices"] >= 1
     if not extra:
+        assert j["multi_cxx"]["equals_resident_shard"] is True and j["multi_cxx"]["pairs_per_call"] == 16, j["multi_cxx"]
         sg = j["scatter_gather"]
         assert sg["ms_per_step"] > 0 and sg["value"] > 0 and sg["chunk"] == 8 and sg["backend"] == "gloo" and 0 <= sg["overlap_frac"] <= 1
         assert j["ms_per_step_median"] >= j["ms_per_step_min"] > 0
@@ -74,6 +75,35 @@ def test_two_ranks_under_torchrun_like_the_driver():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["rccl"]["ranks_seen"] == 2
     assert "error" not in j["scatter_gather"] and j["scatter_gather"]["ms_per_step"] > 0, j["scatter_gather"]
+
+
+def test_eight_ranks_under_torchrun_on_one_gpu():
+    """The driver's N = 8 launch line on a one-GPU box (gloo: the eight ranks share the device, the numbers mean nothing): rank
+    identity over all eight ranks, the chunked scatter/gather leg in its child processes, the one-process C++ leg
+    (sbm_compute_batch_multi over the visible devices, checked against rank 0's resident shard) and a wall time far inside any
+    driver limit -- so that the first real 8-GPU run is not also the first run of this control flow."""
+    import socket
+    import time
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--pairs", "8",
+                        "--no-cpu-baseline", "--sg-timeout", "150"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, SBM_BENCH_BACKEND="gloo"))
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["global_pairs_per_step"] == 64 and j["value"] > 0
+    assert j["rccl"]["ranks_seen"] == 8 and j["rccl"]["backend"] == "gloo"
+    sg = j["scatter_gather"]
+    assert "error" not in sg and sg["ms_per_step"] > 0 and sg["value"] > 0, sg
+    mc = j["multi_cxx"]
+    assert "error" not in mc, mc
+    assert mc["api"] == "sbm_compute_batch_multi" and mc["devices"] >= 1 and mc["pairs_per_call"] == 64 and mc["equals_resident_shard"] is True
+    assert wall < 420, wall
 
 
 @pytest.mark.parametrize("fault", ["hang", "crash"])
