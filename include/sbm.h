@@ -42,7 +42,7 @@
  * and up to 256 disparities -- block sizes 29 / 31 and 257..512 disparities then fall to the sliding-sum kernel (8-25x slower; the
  * kernel name, sbm_last_kernel_name(), then reads "sad_wide_kernel [in-place accumulate unavailable]").
  *
- * Environment. The library reads these seven variables (nothing else); an integrator never needs to set any of them:
+ * Environment. The library reads these eight variables (nothing else); an integrator never needs to set any of them:
  *   variable            default  read      who sets it, and what for
  *   SBM_FAST_INPLACE    1        once      0 = run the two-accumulator build of the SAD kernel (the fallback that is taken
  *                                          automatically when the device self-test of the in-place v_mqsad accumulate
@@ -60,6 +60,14 @@
  *                                          tests / A-B measurements
  *   SBM_WIDE            1        per call  0 = configurations outside the fast envelope run the per-column kernel
  *                                          (sbm_sad_generic.hip) instead of the sliding-sum one (sbm_sad_wide.hip); GPU tests
+ *   SBM_CV_READING      0        per call  bit mask of ALTERNATIVE readings of cv::StereoBM behaviours that this engine restates from
+ *                                          memory and nothing in the reference can pin: 1 = getValidDisparityROI
+ *                                          subtracts minDisparity from roi2's right edge (2.4 lineage), 2 = the LR check reads the cost
+ *                                          plane as `short`, 4 = speckleRange * 16, 8 = the last row of an odd-height image is
+ *                                          prefiltered instead of filled with preFilterCap, 16 = LR check: equal cost -> the later x
+ *                                          wins. The oracle has the same bits; tests/golden/pin_kit.npz holds this engine's outputs
+ *                                          under both readings of each, and tools/verify_with_opencv.py (numpy + cv2 only) names the
+ *                                          reading a given OpenCV implements -- adopting it is a default flip here, not a rewrite
  * Tuning knobs of the measurement scripts (SBM_FAST_NSEG, SBM_FAST_TAPER, SBM_FAST_UNIQ_PLAIN,
  * SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*; the interior kernel's are listed in
  * u96-slam_amd/csrc/sbm_sad_fast_dev.h) exist only in development builds (-DSBM_DEV, tools/exp/r05_devlib.sh); this library

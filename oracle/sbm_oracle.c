@@ -23,6 +23,13 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int iabs(int a) { return a < 0 ? -a : a; }
 static inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* Alternative readings of the OpenCV behaviours this restatement recalls from memory and nothing in the reference can pin
+ * (SURVEY.md A.7 + getValidDisparityROI): one bit each, 0 = the reading the oracle and the engine default to. Process-global,
+ * set by the tests / tools/pin_kit.py only (sbm_oracle.h: SBMO_READ_*). The engine has the same bits (SBM_CV_READING). */
+static int g_reading = 0;
+void sbmo_set_reading(int mask) { g_reading = mask; }
+int sbmo_get_reading(void) { return g_reading; }
+
 /* ------------------------------------------------------------------------------------------------
  * Prefilter, OpenCV flavour.  Follows prefilterXSobel() in OpenCV calib3d stereobm.cpp:
  *   tab(v) = v < -cap ? 0 : v > cap ? 2*cap : v + cap
@@ -51,7 +58,20 @@ void sbmo_prefilter_xsobel(const uint8_t* src, size_t sstride, uint8_t* dst, siz
       d1[x] = xsobel_tab(g1 + 2 * g2 + g3, cap);
     }
   }
-  for (; y < height; y++) memset(dst + (size_t)y * dstride, val0, (size_t)width);
+  for (; y < height; y++) {
+    if ((g_reading & SBMO_READ_ODD_ROW_COMPUTED) && height > 1) {   /* alternative: the leftover row like any other (reflect-101 below) */
+      const uint8_t* r1 = src + (size_t)y * sstride;
+      const uint8_t* r0 = r1 - sstride;
+      uint8_t* d0 = dst + (size_t)y * dstride;
+      d0[0] = d0[width - 1] = val0;
+      for (int x = 1; x < width - 1; x++) {
+        int g0 = r0[x + 1] - r0[x - 1], g1 = r1[x + 1] - r1[x - 1];
+        d0[x] = xsobel_tab(g0 + 2 * g1 + g0, cap);
+      }
+      continue;
+    }
+    memset(dst + (size_t)y * dstride, val0, (size_t)width);
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -90,7 +110,7 @@ void sbmo_valid_roi(const int32_t roi1[4], const int32_t roi2[4], int min_dispar
   int sw2 = block_size / 2;
   int maxd = min_disparity + num_disparities - 1;
   int xmin = imax(roi1[0], roi2[0] + maxd) + sw2;
-  int xmax = imin(roi1[0] + roi1[2], roi2[0] + roi2[2]) - sw2;
+  int xmax = imin(roi1[0] + roi1[2], roi2[0] + roi2[2] - ((g_reading & SBMO_READ_ROI_MINUS_MIND) ? min_disparity : 0)) - sw2;
   int ymin = imax(roi1[1], roi2[1]) + sw2;
   int ymax = imin(roi1[1] + roi1[3], roi2[1] + roi2[3]) - sw2;
   int w = xmax - xmin, h = ymax - ymin;
@@ -353,9 +373,9 @@ void sbmo_validate_disparity(int16_t* disp, size_t dstride, const int32_t* cost,
     for (int x = minX1; x < maxX1; x++) {
       int d = dp[x];
       if (d == INVALID) continue;
-      int c = cp[x];
+      int c = (g_reading & SBMO_READ_COST_SHORT) ? (int)(short)cp[x] : cp[x];
       int x2 = x - ((d + DISP_SCALE / 2) >> DISP_SHIFT);
-      if (cost2[x2] > c) {
+      if ((g_reading & SBMO_READ_LR_TIE_LATER) ? cost2[x2] >= c : cost2[x2] > c) {
         cost2[x2] = c;
         disp2[x2] = d;
       }
@@ -574,7 +594,8 @@ int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const
     }
   }
   if (p->speckle_range >= 0 && p->speckle_window_size > 0)
-    sbmo_filter_speckles(disp, dstride, width, height, FILTERED, p->speckle_window_size, p->speckle_range);
+    sbmo_filter_speckles(disp, dstride, width, height, FILTERED, p->speckle_window_size,
+                         (g_reading & SBMO_READ_SPECKLE_X16) ? p->speckle_range * 16 : p->speckle_range);
   free(pl);
   free(pr);
   free(cost);

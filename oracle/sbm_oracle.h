@@ -59,6 +59,16 @@ void sbmo_prefilter_xsobel_fpga(const uint8_t* src, size_t sstride, uint8_t* dst
                                 int height, uint8_t fill);
 
 /* OpenCV getValidDisparityROI (stereosgbm.cpp). roi = {x,y,w,h}; out all-zero when empty. */
+/* Alternative readings of cv::StereoBM behaviours recalled from memory that nothing in the reference pins (SURVEY.md A.7 +
+ * getValidDisparityROI's 2.4 lineage). 0 = the default reading. Process-global; the engine has the same bits (SBM_CV_READING). */
+#define SBMO_READ_ROI_MINUS_MIND 1     /* getValidDisparityROI: roi2's right edge loses minDisparity */
+#define SBMO_READ_COST_SHORT 2         /* validateDisparity reads the cost plane as `short` (wraps beyond 32767) */
+#define SBMO_READ_SPECKLE_X16 4        /* filterSpeckles gets speckleRange * 16 */
+#define SBMO_READ_ODD_ROW_COMPUTED 8   /* prefilterXSobel computes the last row of an odd-height image */
+#define SBMO_READ_LR_TIE_LATER 16      /* validateDisparity: equal cost -> the later x takes the slot */
+void sbmo_set_reading(int mask);
+int sbmo_get_reading(void);
+
 void sbmo_valid_roi(const int32_t roi1[4], const int32_t roi2[4], int min_disparity, int num_disparities,
                     int block_size, int32_t out[4]);
 

@@ -160,6 +160,27 @@ def lib():
     return _LIB
 
 
+READ_ROI_MINUS_MIND, READ_COST_SHORT, READ_SPECKLE_X16, READ_ODD_ROW_COMPUTED, READ_LR_TIE_LATER = 1, 2, 4, 8, 16
+
+
+class reading:
+    """with sbm_oracle.reading(mask): ... -- the oracle under an alternative reading of the cv::StereoBM behaviours nothing in the
+    reference pins (sbm_oracle.h SBMO_READ_*; process-global, so not for concurrent use)."""
+
+    def __init__(self, mask):
+        self.mask = int(mask)
+
+    def __enter__(self):
+        L = lib()
+        self.prev = L.sbmo_get_reading()
+        L.sbmo_set_reading(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        lib().sbmo_set_reading(self.prev)
+        return False
+
+
 def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 

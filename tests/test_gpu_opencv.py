@@ -99,6 +99,24 @@ def test_engine_reproduces_the_pin_kit(pkg):
             assert np.array_equal(got, kit[f"{name}/{st}"]), (name, str(st), int((got != kit[f"{name}/{st}"]).sum()))
 
 
+def test_engine_reproduces_the_alternative_readings_of_the_kit(pkg, monkeypatch):
+    """Kit v2: the engine under each bit of SBM_CV_READING (the alternative reading of a cv::StereoBM behaviour nobody could pin)
+    still produces what the kit stores for the cases that tell the readings apart."""
+    kit = _kit()
+    fields = [str(f) for f in kit["fields"]]
+    n = 0
+    for b, cs in zip(kit["risk_bits"].tolist(), kit["risk_cases"].tolist()):
+        monkeypatch.setenv("SBM_CV_READING", str(int(b)))
+        for name in str(cs).split(","):
+            p = dict(zip(fields, kit[f"{name}/params"].tolist()))
+            for st in kit["stages"]:
+                got = _engine(pkg, _stage(p, str(st))).compute(kit[f"{name}/left"], kit[f"{name}/right"])
+                want = kit[f"{name}/alt{b}/{st}"]
+                assert np.array_equal(got, want), (name, int(b), str(st), int((got != want).sum()))
+                n += 1
+    assert n >= 4 * 11
+
+
 def test_pin_kit_against_opencv():
     """The one-command pin, run in-tree where a box has cv2: every risk case, first differing stage reported."""
     cv2 = _cv2()

@@ -33,7 +33,11 @@ def test_manifest_hashes(kit):
     assert sorted(want) == sorted(str(n) for n in kit["names"])
     for name in want:
         h = hashlib.sha256()
-        for key in ("left", "right", "params", *[str(s) for s in kit["stages"]]):
+        keys = ["left", "right", "params", *[str(s) for s in kit["stages"]]]
+        for b, cs in zip(kit["risk_bits"].tolist(), kit["risk_cases"].tolist()):      # kit v2: the alternative readings, in bit order
+            if name in str(cs).split(","):
+                keys += [f"alt{b}/{s}" for s in kit["stages"]]
+        for key in keys:
             h.update(np.ascontiguousarray(kit[f"{name}/{key}"]).tobytes())
         assert h.hexdigest() == want[name], name
 
@@ -56,7 +60,22 @@ def test_oracle_reproduces_every_stage(kit, oracle):
                                     (q["roi2_x"], q["roi2_y"], q["roi2_w"], q["roi2_h"]))
             assert np.array_equal(oracle.compute(po, L, R), kit[f"{name}/{st}"]), (name, str(st))
             n += 1
+            for b, cs in zip(kit["risk_bits"].tolist(), kit["risk_cases"].tolist()):   # kit v2: the oracle under the alternative reading
+                if name in str(cs).split(","):
+                    with oracle.reading(int(b)):
+                        assert np.array_equal(oracle.compute(po, L, R), kit[f"{name}/alt{b}/{st}"]), (name, str(st), int(b))
     assert n >= 4 * 20
+
+
+def test_every_risk_has_a_case_that_tells_the_readings_apart(kit):
+    """Kit v2: for each bit of SBM_CV_READING at least one case's stored outputs differ between the default and the alternative
+    reading -- otherwise running the verifier could not name the reading."""
+    assert kit["risk_bits"].tolist() == [1, 2, 4, 8, 16]
+    for b, cs in zip(kit["risk_bits"].tolist(), kit["risk_cases"].tolist()):
+        apart = 0
+        for name in str(cs).split(","):
+            apart += any(not np.array_equal(kit[f"{name}/alt{b}/{st}"], kit[f"{name}/{st}"]) for st in kit["stages"])
+        assert apart >= 1, b
 
 
 def test_kit_covers_the_risk_list(kit):
@@ -117,3 +136,14 @@ def test_verifier_runs_end_to_end_with_a_stand_in(kit, oracle, monkeypatch, caps
             assert rc == 0 and "ALL CASES AGREE" in out
         else:
             assert rc == 1 and "FIRST DIFFERENCE at stage s2_lr" in out and "stage s0_wta" not in out and "stage s1_uniq" not in out
+    # a stand-in that implements ALTERNATIVE readings (speckleRange x 16 and the later-x LR tie): the verifier must name the bits
+    fake = types.ModuleType("cv2")
+    fake.__version__ = "stand-in (alternative readings 4 + 16)"
+    fake.StereoBM_create = lambda numDisparities=0, blockSize=21: FakeBM(numDisparities, blockSize, False)
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    monkeypatch.setattr(sys, "argv", ["verify_with_opencv.py", str(KIT)])
+    with oracle.reading(4 | 16):
+        rc = ver.main()
+    out = capsys.readouterr().out
+    assert rc == 1 and "ALTERNATIVE READING bit 4 matches" in out and "ALTERNATIVE READING bit 16 matches" in out
+    assert "default to 20" in out     # (other cases differ too -- a consequence of the same readings, which the verifier says)

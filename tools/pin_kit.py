@@ -15,7 +15,12 @@ at a time, so that a difference names the first stage that disagrees:
   s1_uniq  + texture threshold and uniqueness ratio of the case
   s2_lr    + disp12MaxDiff of the case
   s3_full  + speckle filter of the case
-Every engine output is also compared with the oracle here; a kit is only written when they agree everywhere."""
+Every engine output is also compared with the oracle here; a kit is only written when they agree everywhere.
+
+Kit v2 (round 6): every risk also has its ALTERNATIVE reading in the engine (environment SBM_CV_READING, sbm_common.h kRead*) and in
+the oracle (sbmo_set_reading); for the cases that can tell the two readings apart the kit carries the engine's outputs under the
+alternative as `<case>/alt<bit>/<stage>`, and `risks` lists (bit, cases, description). tools/verify_with_opencv.py then NAMES the
+reading a given OpenCV implements; adopting it is a default flip of one bit, not a rewrite."""
 import argparse
 import hashlib
 import pathlib
@@ -28,6 +33,14 @@ FIELDS = ("prefilter_type", "prefilter_size", "prefilter_cap", "block_size", "mi
           "uniqueness_ratio", "speckle_window_size", "speckle_range", "disp12_max_diff", "roi1_x", "roi1_y", "roi1_w", "roi1_h",
           "roi2_x", "roi2_y", "roi2_w", "roi2_h")
 STAGES = ("s0_wta", "s1_uniq", "s2_lr", "s3_full")
+# bit of SBM_CV_READING / sbmo_set_reading -> (cases that can tell the readings apart, what the alternative reading is)
+RISKS = {
+    1: (("mind_neg8_rois", "mind_pos4_rois"), "getValidDisparityROI: xmax = min(roi1 right edge, roi2 right edge - minDisparity) - w/2 (OpenCV 2.4 lineage)"),
+    2: (("cost_wrap_ramps",), "validateDisparity sees the block-matching cost plane as `short`: sums beyond 32 767 wrap"),
+    4: (("speckle_range1", "speckle_range16"), "filterSpeckles receives speckleRange * 16 (StereoSGBM's convention)"),
+    8: (("odd_height",), "prefilterXSobel computes the last row of an odd-height image (reflect-101) instead of filling it with preFilterCap"),
+    16: (("lr_ties_d12_0", "lr_ties_d12_1", "lr_ties_d12_2"), "validateDisparity: on equal cost the LATER x takes the right-view slot ('>=' instead of '>')"),
+}
 
 
 def params(nd=64, w=21, cap=31, mind=0, tex=10, uniq=10, spw=50, spr=32, d12=1, ptype=1, psize=9, roi1=(0, 0, 0, 0), roi2=(0, 0, 0, 0)):
@@ -82,6 +95,25 @@ def slant_pair(W, H, nd):
     return np.clip(L, 0, 255).astype(np.uint8), np.clip(np.rint(R), 0, 255).astype(np.uint8)
 
 
+def ramp_pair(W, H, blk=24):
+    """Opposed sawtooth ramps whose slope changes every `blk` columns and every 16 rows: the left image rises along x (x-Sobel clips
+    at +cap nearly everywhere), the right one falls (-cap), so EVERY disparity's window sum is close to its maximum w^2 * 2 * cap --
+    winners with costs on both sides of 32 767 and many different disparities competing for the same right-view columns, which is
+    what a `short` cost plane would decide differently (A.7 item 2; ordinary frames never get there: their minima are far below)."""
+    rng = np.random.default_rng(81)
+
+    def saw(sign):
+        out = np.zeros((H, W), np.int64)
+        for r0 in range(0, H, 16):
+            slopes = rng.integers(5, 14, (W + blk - 1) // blk)
+            acc = np.cumsum(np.repeat(slopes, blk)[:W]) + rng.integers(0, 256)
+            out[r0:r0 + 16] = acc[None, :] + (np.arange(min(16, H - r0))[:, None] * int(rng.integers(1, 7)))
+        v = (out + rng.integers(0, 4, (H, W))) % 256
+        return v if sign > 0 else 255 - v
+
+    return saw(1).astype(np.uint8), saw(-1).astype(np.uint8)
+
+
 def patch_pair(synth, W, H, nd):
     """Textured pair with constant patches (texture sum 0 there) and faint-texture patches around the threshold."""
     L, R = synth.make_batch(905, 1, W, H, nd)
@@ -118,6 +150,8 @@ def cases(golden, synth):
     out.append(("cost_w17_cap63", *s64, params(64, 17, cap=63), "A.7 item 2: 36 414 > 32 767 -- a short cost plane wraps, the LR check sees it"))
     out.append(("cost_w23_cap31", *s64, params(64, 23), "32 798 > 32 767 by a hair"))
     out.append(("cost_w27_cap31", *s64, params(64, 27), "45 198"))
+    out.append(("cost_wrap_ramps", *ramp_pair(320, 96), params(32, 27, tex=0, uniq=0, spw=0, spr=0, d12=1),
+                "opposed ramps, 27 x 27 at cap 31 (45 198): winning costs on both sides of 32 767 -- the case that tells a `short` cost plane from an exact one"))
     out.append(("odd_height", *synth_pair(901, 320, 97, 64), params(64, 15), "A.7 item 3: odd H, last prefilter row = cap"))
     sl = slant_pair(320, 96, 64)
     out.append(("speckle_range1", *sl, params(64, 9, tex=0, uniq=5, spw=150, spr=1), "A.7 item 1: speckleRange 1 (x16 if the range were scaled)"))
@@ -156,11 +190,13 @@ def main():
     from u96_slam_amd import synth
 
     golden = np.load(ROOT / "tests" / "golden" / "ref_pair_640x480.npz")
+    import os
+
     blob, lines = {}, []
     names = []
-    for name, L, R, p, why in cases(golden, synth):
-        names.append(name)
-        blob[f"{name}/left"], blob[f"{name}/right"], blob[f"{name}/params"] = L, R, flat(p)
+    told_apart = {b: 0 for b in RISKS}
+
+    def run_stages(L, R, p, reading):
         outs = []
         for st in STAGES:
             q = stage_params(p, st)
@@ -169,18 +205,47 @@ def main():
             bm.setMinDisparity(q["min_disparity"]); bm.setTextureThreshold(q["texture_threshold"]); bm.setUniquenessRatio(q["uniqueness_ratio"])
             bm.setSpeckleWindowSize(q["speckle_window_size"]); bm.setSpeckleRange(q["speckle_range"]); bm.setDisp12MaxDiff(q["disp12_max_diff"])
             bm.setROI1(q["roi1"]); bm.setROI2(q["roi2"])
-            got = bm.compute(L, R)
+            os.environ["SBM_CV_READING"] = str(reading)        # (read per call by the engine)
+            try:
+                got = bm.compute(L, R)
+            finally:
+                os.environ.pop("SBM_CV_READING", None)
             po = sbm_oracle.make_params(q["num_disparities"], q["block_size"], q["prefilter_cap"], q["min_disparity"], q["texture_threshold"],
                                         q["uniqueness_ratio"], q["speckle_window_size"], q["speckle_range"], q["disp12_max_diff"],
                                         q["prefilter_type"], q["prefilter_size"], q["roi1"], q["roi2"])
-            ref = sbm_oracle.compute(po, L, R)
+            with sbm_oracle.reading(reading):
+                ref = sbm_oracle.compute(po, L, R)
             if not np.array_equal(got, ref):
-                raise SystemExit(f"{name} {st}: engine and oracle differ in {(got != ref).sum()} pixels -- no kit written")
-            blob[f"{name}/{st}"] = got
+                raise SystemExit(f"{name} {st} reading {reading}: engine and oracle differ in {(got != ref).sum()} pixels -- no kit written")
             outs.append(got)
-        d = digest([L, R, flat(p), *outs])
-        lines.append(f"{d}  {name}  {L.shape[1]}x{L.shape[0]}  valid(s3)={float((outs[-1] > (p['min_disparity'] - 1) * 16).mean()):.3f}  # {why}")
+        return outs, bm
+
+    for name, L, R, p, why in cases(golden, synth):
+        names.append(name)
+        blob[f"{name}/left"], blob[f"{name}/right"], blob[f"{name}/params"] = L, R, flat(p)
+        outs, bm = run_stages(L, R, p, 0)
+        for st, got in zip(STAGES, outs):
+            blob[f"{name}/{st}"] = got
+        hashed = [L, R, flat(p), *outs]
+        alts = []
+        for bit, (risk_cases, _) in RISKS.items():
+            if name in risk_cases:
+                aouts, _bm = run_stages(L, R, p, bit)
+                for st, got in zip(STAGES, aouts):
+                    blob[f"{name}/alt{bit}/{st}"] = got
+                hashed += aouts
+                ndiff = sum(int((a != b).sum()) for a, b in zip(aouts, outs))
+                told_apart[bit] += ndiff > 0
+                alts.append(f"alt{bit}:{ndiff}px")
+        d = digest(hashed)
+        lines.append(f"{d}  {name}  {L.shape[1]}x{L.shape[0]}  valid(s3)={float((outs[-1] > (p['min_disparity'] - 1) * 16).mean()):.3f}  {' '.join(alts)}  # {why}")
         print(lines[-1], flush=True)
+    for bit, n in told_apart.items():
+        if n == 0:
+            raise SystemExit(f"no case of the kit tells reading bit {bit} from the default -- no kit written")
+    blob["risk_bits"] = np.array(sorted(RISKS), np.int32)
+    blob["risk_cases"] = np.array([",".join(RISKS[b][0]) for b in sorted(RISKS)])
+    blob["risk_text"] = np.array([RISKS[b][1] for b in sorted(RISKS)])
     blob["names"] = np.array(names)
     blob["fields"] = np.array(FIELDS)
     blob["stages"] = np.array(STAGES)

@@ -4,7 +4,11 @@ repository.  usage: python verify_with_opencv.py pin_kit.npz
 
 For every case of the kit it runs cv2.StereoBM with the stored parameters on the stored inputs, stage by stage (filters switched
 on one at a time), and prints OK or the FIRST stage that differs from the stored output of the MI355X engine, with the number of
-differing pixels and the first differing (row, column, engine value, OpenCV value). Exit code 0 = every case agrees."""
+differing pixels and the first differing (row, column, engine value, OpenCV value). Exit code 0 = every case agrees.
+
+Kit v2: for the behaviours the engine restates from memory the kit also holds the engine's output under the ALTERNATIVE reading
+(`<case>/alt<bit>/<stage>`, one bit of SBM_CV_READING each). A case that differs from the default but equals an alternative is
+reported as such, and the summary names the bits to flip (u96-slam_amd/csrc/sbm_common.h kRead*, oracle/sbm_oracle.h SBMO_READ_*)."""
 import sys
 
 import numpy as np
@@ -39,23 +43,43 @@ def main():
     fields = [str(f) for f in kit["fields"]]
     print("OpenCV", cv2.__version__, "--", len(kit["names"]), "cases")
     bad = 0
+    risk = {}
+    if "risk_bits" in kit.files:
+        for b, cs, txt in zip(kit["risk_bits"].tolist(), kit["risk_cases"].tolist(), kit["risk_text"].tolist()):
+            for c in str(cs).split(","):
+                risk.setdefault(c, []).append((int(b), str(txt)))
+    flips = {}
     for name in kit["names"]:
         name = str(name)
         p = dict(zip(fields, kit[f"{name}/params"].tolist()))
         L, R = kit[f"{name}/left"], kit[f"{name}/right"]
+        got_all = {str(st): make_bm(cv2, stage_params(p, str(st))).compute(L, R) for st in kit["stages"]}
         verdict = "OK"
         for st in kit["stages"]:
             st = str(st)
-            want = kit[f"{name}/{st}"]
-            got = make_bm(cv2, stage_params(p, st)).compute(L, R)
+            want, got = kit[f"{name}/{st}"], got_all[st]
             if not np.array_equal(got, want):
-                ys, xs = np.nonzero(got != want)
-                verdict = (f"FIRST DIFFERENCE at stage {st}: {len(ys)} pixels, first at row {ys[0]} column {xs[0]}: "
-                           f"engine {int(want[ys[0], xs[0]])}, OpenCV {int(got[ys[0], xs[0]])}; rows {ys.min()}..{ys.max()}, columns {xs.min()}..{xs.max()}")
+                alt = [(b, txt) for b, txt in risk.get(name, []) if all(np.array_equal(got_all[str(s2)], kit[f"{name}/alt{b}/{s2}"]) for s2 in kit["stages"])]
+                if alt:
+                    b, txt = alt[0]
+                    verdict = f"ALTERNATIVE READING bit {b} matches at every stage: {txt}"
+                    flips[b] = txt
+                else:
+                    ys, xs = np.nonzero(got != want)
+                    verdict = (f"FIRST DIFFERENCE at stage {st}: {len(ys)} pixels, first at row {ys[0]} column {xs[0]}: "
+                               f"engine {int(want[ys[0], xs[0]])}, OpenCV {int(got[ys[0], xs[0]])}; rows {ys.min()}..{ys.max()}, columns {xs.min()}..{xs.max()}")
                 bad += 1
                 break
         print(f"{name:24s} {verdict}")
-    print("ALL CASES AGREE: the engine's block-matching output is pinned to this OpenCV build" if bad == 0 else f"{bad} case(s) differ")
+    if bad == 0:
+        print("ALL CASES AGREE: the engine's block-matching output is pinned to this OpenCV build")
+    else:
+        print(f"{bad} case(s) differ")
+        if flips:
+            print("(cases reported as FIRST DIFFERENCE may simply follow from the alternative readings below: the kit only stores the "
+                  "alternatives for the cases built to tell them apart -- flip, regenerate, re-run)")
+            print("this OpenCV implements the alternative reading of: " + "; ".join(f"bit {b} ({t})" for b, t in sorted(flips.items())))
+            print(f"-> make SBM_CV_READING / sbmo_set_reading default to {sum(flips)} (sbm_api.hip: env_switch(\"SBM_CV_READING\", ...); oracle g_reading), regenerate the kit")
     return 1 if bad else 0
 
 

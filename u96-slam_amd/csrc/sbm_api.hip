@@ -401,13 +401,13 @@ int sbm_set_profiling(sbm_handle* h, int enabled) {
 }
 
 // cv getValidDisparityROI (calib3d stereosgbm.cpp) with cv::StereoBM's "empty rect = whole image" substitution.
-static void valid_roi(const sbm_params& p, int W, int H, int roi[4]) {
+static void valid_roi(const sbm_params& p, int W, int H, int reading, int roi[4]) {
   int full[4] = {0, 0, W, H};
   const int* r1 = (p.roi1[2] > 0 && p.roi1[3] > 0) ? p.roi1 : full;
   const int* r2 = (p.roi2[2] > 0 && p.roi2[3] > 0) ? p.roi2 : full;
   const int sw2 = p.block_size / 2, maxd = p.min_disparity + p.num_disparities - 1;
   const int xmin = std::max(r1[0], r2[0] + maxd) + sw2;
-  const int xmax = std::min(r1[0] + r1[2], r2[0] + r2[2]) - sw2;
+  const int xmax = std::min(r1[0] + r1[2], r2[0] + r2[2] - ((reading & kReadRoiMinusMinD) ? p.min_disparity : 0)) - sw2;
   const int ymin = std::max(r1[1], r2[1]) + sw2;
   const int ymax = std::min(r1[1] + r1[3], r2[1] + r2[3]) - sw2;
   if (xmax - xmin > 0 && ymax - ymin > 0) {
@@ -501,7 +501,8 @@ int sbm_compute_device(sbm_handle* h, int n, const void* d_left, const void* d_r
   int16_t* out = (int16_t*)d_disp;
 
   int roi[4];
-  valid_roi(p, width, height, roi);
+  g.reading = env_switch("SBM_CV_READING", 0);
+  valid_roi(p, width, height, g.reading, roi);
   g.row0 = std::max(roi[1], 0); g.row1 = std::min(roi[1] + roi[3], height);
   g.col0 = std::max(std::min(roi[0], width), 0); g.col1 = std::max(std::min(roi[0] + roi[2], width), 0);
   const bool range_fits = !(g.lofs >= width || g.rofs >= width || g.width1 < 1);

@@ -12,7 +12,7 @@ namespace sbm {
 // Environment switches of the library -- the complete list, documented for integrators in include/sbm.h ("Environment").
 //   env_switch(): read in every build. They select a tested fallback or a code path that the GPU tests compare with the
 //                 default one: SBM_FAST_INPLACE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS, SBM_SPECKLE_BAND,
-//                 SBM_HOST_ZEROCOPY, SBM_WIDE.
+//                 SBM_HOST_ZEROCOPY, SBM_WIDE, SBM_CV_READING.
 //   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_NSEG, SBM_FAST_TAPER,
 //                 SBM_FAST_UNIQ_PLAIN, SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*): compiled in
 //                 only with -DSBM_DEV (the development library of tools/exp/r05_devlib.sh; sbm_sad_fast_dev.h lists the interior
@@ -44,7 +44,17 @@ struct Geom {
   int want_cost;       // disp12_max_diff >= 0
   int cost16;          // the cost plane holds uint16 (fast + border kernels: sums <= 65534) instead of int32
   int pfshift;         // the prefiltered planes hold (value << pfshift) + 1 (0 unless the fast path asks for it)
+  int reading;         // SBM_CV_READING: alternative readings of cv::StereoBM behaviours nobody could pin (kRead* bits; 0 = default)
 };
+
+// The bits of SBM_CV_READING (include/sbm.h): every behaviour of cv::StereoBM that this engine restates from
+// memory and that the reference's data cannot pin has its alternative reading behind one bit here AND in the CPU oracle
+// (sbmo_set_reading), so that the day somebody runs tools/verify_with_opencv.py the fix is a default flip.
+constexpr int kReadRoiMinusMinD = 1;      // getValidDisparityROI: xmax = min(roi1 right edge, roi2 right edge - minDisparity) - w/2 (2.4 lineage)
+constexpr int kReadCostShort = 2;         // validateDisparity sees the block-matching cost plane as `short` (wraps beyond 32767)
+constexpr int kReadSpeckleX16 = 4;        // filterSpeckles receives speckleRange * 16 (StereoSGBM's convention)
+constexpr int kReadOddRowComputed = 8;    // prefilterXSobel: the last row of an odd-height image is computed, not filled with cap
+constexpr int kReadLrTieLater = 16;       // validateDisparity: on equal cost the LATER x takes the slot
 
 // Prefiltered planes store value+1 (range 1..2*cap+1 <= 127) so that 0 can act as the "masked byte" of
 // v_mqsad_pk_u16_u8; padding bytes are 0. sbm_debug_fetch() removes the bias again.

@@ -26,6 +26,7 @@ struct LrArgs {
   int cost16;
   int W, H, mindisp, nd, tol, filtered, row0, row1, col0, col1, do_lr;
   int cx0, cx1;  // columns [cx0,cx1) of disp_pre were computed; the rest reads as FILTERED
+  int cost_short, tie_later;   // alternative readings (sbm_common.h kRead*): generic kernel only
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned long long lr_keys[];
@@ -54,8 +55,12 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
     const int d = dp[x];
     if (d == INV) continue;
     const int x2 = x - ((d + 8) >> 4);
-    if (x2 >= 0 && x2 < a.W)
-      atomicMin(&lr_keys[x2], ((unsigned long long)(a.cost16 ? (unsigned)cp16[x] : (unsigned)cp32[x]) << 32) | (unsigned)x);
+    if (x2 >= 0 && x2 < a.W) {
+      unsigned c = a.cost16 ? (unsigned)cp16[x] : (unsigned)cp32[x];
+      if (a.cost_short) c = (unsigned)((int)(short)c + 32768);            // order of the wrapped `short`
+      // cheapest claimant, then the earliest x (cv's strict '>'); tie_later: then the latest x
+      atomicMin(&lr_keys[x2], ((unsigned long long)c << 32) | (unsigned)(a.tie_later ? a.W - 1 - x : x));
+    }
   }
   __syncthreads();
   for (int x = threadIdx.x; x < a.W; x += 256) {
@@ -68,14 +73,16 @@ __global__ void __launch_bounds__(256) lrcheck_kernel(LrArgs a) {
       if (xa >= 0 && xa < a.W) {
         const unsigned long long k = lr_keys[xa];
         if (k != ~0ull) {
-          const int d2 = dp[(int)(k & 0xffffffffu)];
+          const int xw = (int)(k & 0xffffffffu);
+          const int d2 = dp[a.tie_later ? a.W - 1 - xw : xw];
           bad_a = abs(d2 - d) > a.tol;
         }
       }
       if (xb >= 0 && xb < a.W) {
         const unsigned long long k = lr_keys[xb];
         if (k != ~0ull) {
-          const int d2 = dp[(int)(k & 0xffffffffu)];
+          const int xw = (int)(k & 0xffffffffu);
+          const int d2 = dp[a.tie_later ? a.W - 1 - xw : xw];
           bad_b = abs(d2 - d) > a.tol;
         }
       }
@@ -246,9 +253,10 @@ hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t*
   a.W = g.W; a.H = g.H; a.mindisp = g.mindisp; a.nd = g.nd; a.tol = disp12_max_diff * 16; a.filtered = g.filtered;
   a.row0 = g.row0; a.row1 = g.row1; a.col0 = g.col0; a.col1 = g.col1; a.do_lr = disp12_max_diff >= 0;
   a.cx0 = g.lofs; a.cx1 = g.lofs + g.xend;
+  a.cost_short = (g.reading & kReadCostShort) != 0; a.tie_later = (g.reading & kReadLrTieLater) != 0;
   // (the 16-bit verdict of lrcheck16_kernel: disparities of one map less than 16384 apart, tolerance clamped to that -- a larger
   // one passes everything either way)
-  if (a.do_lr && g.cost16 && g.W <= 4096 && (g.nd + 1) * 16 <= 16384) {
+  if (a.do_lr && g.cost16 && g.W <= 4096 && (g.nd + 1) * 16 <= 16384 && !a.cost_short && !a.tie_later) {
     a.tol = std::min(a.tol, 16384);
     const size_t lds16 = (size_t)(g.W + 3 + 64 + 8) * sizeof(unsigned);   // claims, pads, per-lane dummy slots
     // PX pixels per thread and iteration, blocks of at most BSMAX threads, the fewest iterations that cover the row with them and
@@ -898,6 +906,7 @@ __global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __rest
 hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* seam, int32_t* nseam, const Geom& g, int max_size,
                           int max_diff, hipStream_t s) {
   dim3 grid((g.H + 3) / 4, g.n);
+  if (g.reading & kReadSpeckleX16) max_diff = (int)std::min<long>((long)max_diff * 16, 1L << 17);
   max_diff = std::min(max_diff, 1 << 17);   // int16 values: any larger range joins everything alike
   const int HS = g.W;   // seam-list slots per band: at most one contact per pixel of the seam
   // Two implementations. Default: band walk (runs + merge in one pass, G rows per wavefront) + seam unions,

@@ -27,6 +27,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 struct PfMap {
   int lo, hi, off, bias, rtl;
   int shift;   // out = ((clip + off) << shift) + bias  (engine planes of the pre-scaled fast path, else 0)
+  int odd_row_cap;   // cv flavour: the last row of an odd-height image is all cap (0: computed like any other row, SBM_CV_READING bit 3)
 };
 __device__ __forceinline__ int clipmap(int v, const PfMap& m) { return (v < m.lo ? m.lo : (v > m.hi ? m.hi : v)) + m.off; }
 
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(const uint8_t* __restric
     const int y = y0 + j;
     if (y >= H) break;
     uint32_t out[4];
-    if (m.rtl ? (y == 0 || y == H - 1) : ((H & 1) && y == H - 1)) {
+    if (m.rtl ? (y == 0 || y == H - 1) : (m.odd_row_cap && (H & 1) && y == H - 1)) {
       out[0] = out[1] = out[2] = out[3] = (uint32_t)(((m.rtl ? 0 : m.off) << m.shift) + m.bias) * 0x01010101u;
     } else {
       // vertical 1-2-1 sums (max 4*255: no carry between the halves), then the horizontal difference
@@ -197,7 +198,7 @@ hipError_t launch_prefilter(const uint8_t* d_left, const uint8_t* d_right, uint8
   const int rows = pf_rows((size_t)4 * g.n * g.W * g.H);
   const int ngroup = (g.H + rows - 1) / rows;
   dim3 grid((npiece * ngroup + 255) / 256, 2 * g.n);
-  const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0, g.pfshift};
+  const PfMap m{-g.cap, g.cap, g.cap, kPfBias, 0, g.pfshift, (g.reading & kReadOddRowComputed) ? 0 : 1};
 #define SBM_PF(R) hipLaunchKernelGGL(prefilter_kernel<R>, grid, dim3(256), 0, s, d_left, d_right, pf_l, pf_r, g.W, g.H, g.pitch, g.padl, \
                      (size_t)g.W * g.H, (size_t)g.plane, (size_t)g.n * g.W * g.H, (size_t)g.n * g.W * g.H, m)
   if (rows == 2) SBM_PF(2); else if (rows == 8) SBM_PF(8); else SBM_PF(4);
@@ -278,7 +279,7 @@ hipError_t launch_prefilter_dense(const uint8_t* d_src, uint8_t* d_dst, int n, i
   const int ngroup = (H + rows - 1) / rows;
   // the kernel addresses images as (pair, side): image j = pair j/2, side j&1, so a dense array of images is a
   // sequence of pairs with a stride of two images; an odd last image goes in a second launch of one side
-  const PfMap m = rtl ? PfMap{-32, 31, 32, 0, 1, 0} : PfMap{-cap, cap, cap, 0, 0, 0};
+  const PfMap m = rtl ? PfMap{-32, 31, 32, 0, 1, 0, 1} : PfMap{-cap, cap, cap, 0, 0, 0, 1};
   const size_t img = (size_t)W * H;
   const unsigned gx = (unsigned)((npiece * ngroup + 255) / 256);
 #define SBM_PFD(R)                                                                                                          \
