@@ -30,6 +30,12 @@ static int g_reading = 0;
 void sbmo_set_reading(int mask) { g_reading = mask; }
 int sbmo_get_reading(void) { return g_reading; }
 
+/* 1: sbmo_compute / sbmo_compute_batch take the u16-vectorised correspondence of sbm_oracle_simd.c where it applies (every window
+ * sum fits 16 bits) -- bench.py's second cpu_baseline figure; the CHECKER stays the scalar restatement (default 0). */
+static int g_simd = 0;
+void sbmo_set_simd(int on) { g_simd = on; }
+int sbmo_get_simd(void) { return g_simd; }
+
 /* ------------------------------------------------------------------------------------------------
  * Prefilter, OpenCV flavour.  Follows prefilterXSobel() in OpenCV calib3d stereobm.cpp:
  *   tab(v) = v < -cap ? 0 : v > cap ? 2*cap : v + cap
@@ -578,8 +584,12 @@ int sbmo_compute(const sbm_params* p, const uint8_t* left, size_t lstride, const
   /* intersect with the image rows, as FindStereoCorrespInvoker does with its stripe rectangle */
   int row0 = imax(roi[1], 0), row1 = imin(roi[1] + roi[3], height);
   if (roi[2] > 0 && roi[3] > 0 && row1 > row0) {
-    sbmo_find_correspondence(pl, pr, (size_t)width, width, height, row0, row1, p, disp, dstride,
-                             p->disp12_max_diff >= 0 ? cost : NULL, (size_t)width);
+    if (g_simd && sbmo_simd_ok(p))
+      sbmo_find_correspondence_u16(pl, pr, (size_t)width, width, height, row0, row1, p, disp, dstride,
+                                   p->disp12_max_diff >= 0 ? cost : NULL, (size_t)width);
+    else
+      sbmo_find_correspondence(pl, pr, (size_t)width, width, height, row0, row1, p, disp, dstride,
+                               p->disp12_max_diff >= 0 ? cost : NULL, (size_t)width);
     if (pre_lr)
       for (int y = row0; y < row1; y++) memcpy(pre_lr + (size_t)y * width, disp + (size_t)y * dstride, (size_t)width * 2);
     if (cost_out && p->disp12_max_diff >= 0) memcpy(cost_out, cost, npix * sizeof(int32_t));

@@ -69,6 +69,16 @@ void sbmo_prefilter_xsobel_fpga(const uint8_t* src, size_t sstride, uint8_t* dst
 void sbmo_set_reading(int mask);
 int sbmo_get_reading(void);
 
+/* u16-vectorised timing variant of the correspondence stage (sbm_oracle_simd.c: what cv::StereoBM's "useShorts" SIMD path
+ * delivers on a CPU). sbmo_set_simd(1) makes sbmo_compute / sbmo_compute_batch use it where sbmo_simd_ok(p); results are
+ * bit-identical to the scalar restatement (tests/test_oracle_properties.py), which stays the checker. */
+void sbmo_set_simd(int on);
+int sbmo_get_simd(void);
+int sbmo_simd_ok(const sbm_params* p);
+void sbmo_find_correspondence_u16(const uint8_t* left_full, const uint8_t* right_full, size_t stride, int width, int height_full,
+                                  int row0, int row1, const sbm_params* p, int16_t* disp_full, size_t dstride, int32_t* cost_full,
+                                  size_t cstride);
+
 void sbmo_valid_roi(const int32_t roi1[4], const int32_t roi2[4], int min_disparity, int num_disparities,
                     int block_size, int32_t out[4]);
 

@@ -87,7 +87,7 @@ def make_params(num_disparities=64, block_size=21, prefilter_cap=31, min_dispari
 
 def build(force=False):
     so = _HERE / "libsbm_oracle.so"
-    srcs = [_HERE / "sbm_oracle.c", _HERE / "sbm_oracle_fpga.c", _HERE / "sbm_oracle.h"]
+    srcs = [_HERE / "sbm_oracle.c", _HERE / "sbm_oracle_fpga.c", _HERE / "sbm_oracle_simd.c", _HERE / "sbm_oracle.h"]
     if force or not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
         subprocess.run(["make", "-C", str(_HERE), "libsbm_oracle.so"], check=True, capture_output=True)
     return so
@@ -179,6 +179,28 @@ class reading:
     def __exit__(self, *exc):
         lib().sbmo_set_reading(self.prev)
         return False
+
+
+class simd:
+    """with sbm_oracle.simd(): compute / compute_batch take the u16-vectorised correspondence stage (sbm_oracle_simd.c) where every
+    window sum fits 16 bits -- a TIMING variant for bench.py's cpu_baseline, bit-identical to the scalar restatement."""
+
+    def __init__(self, on=True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        L = lib()
+        self.prev = L.sbmo_get_simd()
+        L.sbmo_set_simd(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        lib().sbmo_set_simd(self.prev)
+        return False
+
+
+def simd_ok(params):
+    return bool(lib().sbmo_simd_ok(ctypes.byref(params)))
 
 
 def _p(a, t):

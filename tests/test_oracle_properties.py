@@ -313,3 +313,27 @@ def test_prefilter_norm_closed_form_equals_incremental_form(oracle, h, w, win, c
     img = rng.integers(0, 256, (h, w), dtype=np.uint8)
     assert h > win // 2
     assert np.array_equal(oracle.prefilter_norm(img, win, cap), _prefilter_norm_incremental(img, win, cap))
+
+
+@pytest.mark.parametrize("cfg", [(320, 96, 64, 15, 0, 10, 10), (301, 77, 48, 9, -8, 0, 0), (260, 71, 32, 21, 4, 25, 200), (200, 60, 16, 5, 0, 5, 0),
+                                 (400, 64, 128, 11, 0, 15, 10), (180, 50, 16, 21, -20, 10, 10)])
+def test_u16_vectorised_variant_equals_the_scalar_restatement(oracle, pkg, cfg):
+    """oracle/sbm_oracle_simd.c (bench.py's second CPU figure: 16-bit sums, key minimum, counting uniqueness test) against the
+    scalar restatement: final maps, pre-LR maps and the cost plane, bit for bit -- windows / disparity counts / minDisparity of
+    either sign / uniqueness 0 and large / texture thresholds, widths and heights that are not multiples of anything."""
+    from u96_slam_amd import synth
+
+    W, H, nd, w, mind, uniq, tex = cfg
+    L, R = synth.make_batch(5, 2, W, H, max(nd, 16))
+    rng = np.random.default_rng(W)
+    L[1] = rng.integers(0, 256, (H, W))          # an uncorrelated pair: ties, failed uniqueness, large sums
+    p = oracle.make_params(nd, w, 31, mind, tex, uniq, 40, 24, 1)
+    assert oracle.simd_ok(p)
+    for i in range(2):
+        st0, a = oracle.compute(p, L[i], R[i], stages=True)
+        with oracle.simd():
+            st1, b = oracle.compute(p, L[i], R[i], stages=True)
+        assert st0 == st1 == 0
+        for k in ("disp", "pre_lr", "cost"):
+            assert np.array_equal(a[k], b[k]), (cfg, i, k, int((a[k] != b[k]).sum()))
+    assert not oracle.simd_ok(oracle.make_params(64, 27, 63))     # 27 * 27 * 126 does not fit 16 bits: the scalar path stays
