@@ -436,10 +436,11 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
   if (need_speckle && !h->spk_nseam) {   // keyed on the LAST buffer of the set: an attempt that failed half way is redone
     hipFree(h->spk_runs); hipFree(h->spk_nheads); hipFree(h->spk_seam);
     h->spk_runs = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr;
-    HIPCHK(h, hipMalloc(&h->spk_runs, npix * 16));
+    // run records: per pair a dense block (16 per row) + the per-pixel plane behind it (sbm_post.hip: spk_slot)
+    HIPCHK(h, hipMalloc(&h->spk_runs, (npix + (size_t)h->cap_n * H * 16) * 16));
     HIPCHK(h, hipMalloc((void**)&h->spk_nheads, (size_t)h->cap_n * H * sizeof(int32_t)));
     const size_t seams = (size_t)h->cap_n * ((H + 1) / 2);
-    HIPCHK(h, hipMalloc((void**)&h->spk_seam, seams * W * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc((void**)&h->spk_seam, seams * ((size_t)W + 32) * sizeof(uint32_t)));   // (+ the dense block: spk_seam_slot)
     HIPCHK(h, hipMalloc((void**)&h->spk_nseam, seams * sizeof(int32_t)));
   }
   return SBM_OK;

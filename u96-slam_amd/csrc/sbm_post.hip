@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
 // and are unioned by speckle_seam_kernel once every band is done.
 //
 // Round 6, data: a RUN is the unit of everything downstream, so runs get compact 16-byte records -- run k of row y lives in
-// slot y * W + k of the pair's record plane: parent (union-find), size (accumulated at the root by
+// slot spk_slot(y, k) of the pair's record area: parent (union-find), size (accumulated at the root by
 // the count kernel), first and last column. A row of a disparity map holds a handful of runs, so its records share one or two
 // cache lines; the round-5 layout (labels and sizes indexed by the PIXEL of the run head, lists elsewhere) cost a cache line
 // of HBM traffic per run and array -- the unions, the count and the apply kernel were chains of DRAM round trips. The k-th
@@ -540,6 +540,23 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
 // kernel -- were built and measured in round 6: the band walk of one pair got shorter by what the seam kernel got longer, and
 // every larger launch lost; profiles/r06_speckle.md.)
 struct SpkRun { int parent, size, first, last; };
+// first: bit 31 marks the root of an IN-BAND component (set by the band walk's last phase). size: at such a root the component's
+// size -- in-band pixels first, then what the count kernel adds for roots hooked under it -- or >= kSpkBig once something
+// larger than maxSpeckleSize is known to touch it; at every other run the in-band size of its component (a hint that lets the
+// later kernels decide the bulk -- runs of components that are large inside their own band -- without leaving the record).
+constexpr int kSpkRootFlag = (int)0x80000000u, kSpkBig = 0x40000000, kSpkMaxSize = 2048;
+// Where the records live. A row of a disparity map holds a handful of runs, and a record plane indexed y * W + k would put every
+// row's few records on a page of its own (19 KB apart at KITTI width): the kernels behind the band walk touch every row once and
+// spent ~10 us each on 24 000 cold TLB entries (64 KITTI pairs). So the first kSpkDense runs of a row live in a dense block (256
+// bytes per row: 6 MB for that batch), only the runs beyond them in the per-pixel plane behind it. Same for the seam lists: the
+// first kSpkDenseSeam contacts of a band's seam in a dense block, the rest in the band's W slots.
+constexpr unsigned kSpkDense = 16, kSpkDenseSeam = 32;
+__device__ __forceinline__ unsigned spk_slot(unsigned y, unsigned k, unsigned W, unsigned H) {
+  return k < kSpkDense ? y * kSpkDense + k : H * kSpkDense + y * W + k;
+}
+__device__ __forceinline__ unsigned spk_seam_slot(unsigned band, unsigned i, unsigned nbands, unsigned HS) {
+  return i < kSpkDenseSeam ? band * kSpkDenseSeam + i : nbands * kSpkDenseSeam + band * HS + i;
+}
 constexpr int SPK_BG = 4;   // chunks loaded up front per row
 constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x10000000;
 
@@ -560,10 +577,10 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
   const int y0 = band * G;
   const size_t plane_off = (size_t)blockIdx.y * W * H;
   const int16_t* d = disp + plane_off;
-  SpkRun* const R = runs + plane_off;
+  SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);   // this pair's records (dense block + plane)
   int* const P = &R->parent;                                   // parent of slot i: P[4 i]
   int2* const list = contact_lds[wave];
-  unsigned* const sl = seam + ((size_t)blockIdx.y * nbands + band) * HS;
+  unsigned* const sl = seam + (size_t)blockIdx.y * ((size_t)nbands * kSpkDenseSeam + (size_t)nbands * HS);   // this pair's seam lists
   int count = 0, nsm = 0;   // uniform: buffered in-band contacts, seam contacts listed so far
   auto flush = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // record stores of this wavefront have left before the unions start
@@ -575,7 +592,6 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
     __builtin_amdgcn_wave_barrier();
     count = 0;
   };
-  const unsigned slot0 = (unsigned)(y0 * W);   // slot of run 0 of the band's first row (rows: + r W)
   const unsigned tm = 2u * (unsigned)maxdiff;
   // substitutes of invalid pixels: rows of even / odd parity (bands start on even rows: G is even)
   const int far_e = kSpkFar + ((lane & 1) ? kSpkFarStep : 0), far_o = kSpkFar + ((lane & 1) ? 0 : kSpkFarStep);
@@ -676,8 +692,8 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
             if (lane_in(fm)) {
               const int k = lanes_below(fm);
               const int ku = run_of(r - 1), kd = run_of(r);
-              if (r < G) list[count + k] = make_int2((int)(slot0 + (unsigned)((r - 1) * W)) + ku, (int)(slot0 + (unsigned)(r * W)) + kd);
-              else *at32(sl, (unsigned)(nsm + k)) = (unsigned)ku | ((unsigned)kd << 16);
+              if (r < G) list[count + k] = make_int2((int)spk_slot(y0 + r - 1, ku, W, H), (int)spk_slot(y0 + r, kd, W, H));
+              else *at32(sl, spk_seam_slot(band, (unsigned)(nsm + k), nbands, HS)) = (unsigned)ku | ((unsigned)kd << 16);
             }
             if (r < G) count += __popcll(fm);
             else nsm += __popcll(fm);
@@ -687,12 +703,11 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
         // invalid pixel) right of a valid one closes the oldest open one -- the k-th start and the k-th end are the same run.
 #pragma unroll
         for (int r = 0; r < G; r++) {
-          const unsigned rs = slot0 + (unsigned)(r * W);
           const unsigned long long hm = head[r];
           const unsigned long long em = __ballot(pv[r] < kSpkFarMin) & (hm | ~vm[r]);
           if (hm) {
             if (lane_in(hm)) {
-              const unsigned self = rs + (unsigned)(nh[r] + lanes_below(hm));
+              const unsigned self = spk_slot(y0 + r, (unsigned)(nh[r] + lanes_below(hm)), W, H);
               int* q = &at32(R, self)->parent;
               // parent = self, size = 0 (accumulated by the count kernel), first column; the last column follows when the run ends
               __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -701,7 +716,7 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
             }
           }
           if (em) {
-            if (lane_in(em)) at32(R, rs + (unsigned)(ne[r] + lanes_below(em)))->last = cb + lane - 1;
+            if (lane_in(em)) at32(R, spk_slot(y0 + r, (unsigned)(ne[r] + lanes_below(em)), W, H))->last = cb + lane - 1;
             ne[r] += __popcll(em);
           }
         }
@@ -726,30 +741,89 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
     for (int r = 0; r < G; r++) {
       const int y = y0 + r;
       if (y < H) {
-        if ((tail >> r) & 1u) at32(R, slot0 + (unsigned)(r * W + ne[r]))->last = ce - 1;
+        if ((tail >> r) & 1u) at32(R, spk_slot(y0 + r, (unsigned)ne[r], W, H))->last = ce - 1;
         nheads[(size_t)blockIdx.y * H + y] = nh[r];
       }
     }
     nseam[(size_t)blockIdx.y * nbands + band] = nsm;
   }
   if (count) flush();
+  // ---- last phase: the band's components are final INSIDE the band. Every run learns the in-band size of its component, every
+  // in-band root is flagged: the seam / count / apply kernels then settle the bulk of the runs from the run's own record.
+  // Lanes = (row of the band, run of that row), 64 / G runs of every row at a time; two sweeps with the band's size sums between.
+  {
+    constexpr int LPR = 64 / G;                      // lanes per row
+    const int q = lane / LPR, li = lane - q * LPR;
+    int nhq = 0;
+#pragma unroll
+    for (int r = 0; r < G; r++) nhq = q == r ? nh[r] : nhq;
+    int nhmax = nh[0];
+#pragma unroll
+    for (int r = 1; r < G; r++) nhmax = max(nhmax, nh[r]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the records' last stores (run ends) have left
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < nhmax; base += LPR) {
+      const int k = base + li;
+      if (k < nhq) {
+        const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
+        SpkRun* const rec = at32(R, self);
+        const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int lst = __hip_atomic_load(&rec->last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int root = uf_find<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, (int)self);
+        if (root != (int)self) __hip_atomic_store(&rec->parent, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // compressed: one step to the in-band root
+        __hip_atomic_fetch_add(&at32(R, (unsigned)root)->size, lst - fst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                          // the size sums are complete
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < nhmax; base += LPR) {
+      const int k = base + li;
+      if (k < nhq) {
+        const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
+        SpkRun* const rec = at32(R, self);
+        const int root = __hip_atomic_load(&rec->parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (root == (int)self) {
+          const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          rec->first = fst | kSpkRootFlag;
+        } else {
+          rec->size = __hip_atomic_load(&at32(R, (unsigned)root)->size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
 }
 
-// seam contacts of the band walk: one wavefront per band, 64 unions at a time
+// Seam contacts of the band walk: one wavefront per band, 64 contacts at a time. Both records of a contact are loaded at once and
+// say how large the two components are INSIDE their bands: both larger than maxSpeckleSize -- the bulk -- and the contact does
+// not matter (neither is a speckle, merged or not); one larger: the other one's in-band root is marked "touches something
+// large" (a plain store; the count kernel carries the mark to the final root if that root gets hooked); both small: union of the
+// two in-band roots.
 __global__ void __launch_bounds__(256) speckle_seam_kernel(SpkRun* __restrict__ runs, const unsigned* __restrict__ seam,
-                                                            const int* __restrict__ nseam, int HS, int W, int H, int G) {
+                                                            const int* __restrict__ nseam, int HS, int W, int H, int G, int maxsize) {
   const int lane = threadIdx.x & 63;
   const int nbands = (H + G - 1) / G;
   const int band = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (band >= nbands) return;
   const int y = band * G + G - 1;   // upper row of the seam
   if (y + 1 >= H) return;
-  int* const P = &(runs + (size_t)blockIdx.y * W * H)->parent;
-  const unsigned* sl = seam + ((size_t)blockIdx.y * nbands + band) * HS;
+  SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);
+  int* const P = &R->parent;
+  const unsigned* sl = seam + (size_t)blockIdx.y * ((size_t)nbands * kSpkDenseSeam + (size_t)nbands * HS);
   const int n = nseam[(size_t)blockIdx.y * nbands + band];
   for (int i = lane; i < n; i += 64) {
-    const unsigned e = sl[i];
-    uf_union<__HIP_MEMORY_SCOPE_AGENT, 4>(P, y * W + (int)(e & 0xffffu), (y + 1) * W + (int)(e >> 16));
+    const unsigned e = sl[spk_seam_slot(band, (unsigned)i, nbands, HS)];
+    const int a = (int)spk_slot(y, e & 0xffffu, W, H), b = (int)spk_slot(y + 1, e >> 16, W, H);
+    const int4 ra = *reinterpret_cast<const int4*>(R + a), rb = *reinterpret_cast<const int4*>(R + b);   // parent, size, first, last
+    // (a record's size is its component's in-band size -- its own sum at a root; marks of this kernel only make it larger)
+    const bool big_a = ra.y > maxsize, big_b = rb.y > maxsize;
+    if (big_a && big_b) continue;
+    if (big_a != big_b) {
+      const int small_root = big_a ? rb.x : ra.x;
+      __hip_atomic_fetch_max(&R[small_root].size, kSpkBig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    uf_union<__HIP_MEMORY_SCOPE_AGENT, 4>(P, ra.x, rb.x);
   }
 }
 
@@ -862,44 +936,59 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
   }
 }
 
-// ---- record-driven count / apply: one wavefront per image row, one lane per run -----------------------------------------
+// ---- record-driven count / apply: one wavefront per image row, one lane per run ---------------------------------------------
+// count: only in-band roots that the seam kernel hooked under another root have anything to do -- their size (or their "touches
+// something large" mark) goes to the final root. Everything else leaves after one load.
 __global__ void __launch_bounds__(256) speckle_count_list_kernel(SpkRun* __restrict__ runs, const int* __restrict__ nheads,
                                                                   int W, int H, int maxsize) {
   SPK_ROW_SETUP
   if (y >= H) return;
-  SpkRun* const R = runs + plane_off;
+  (void)plane_off;
+  SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);
   int* const P = &R->parent;
   const int nh = nheads[(size_t)blockIdx.y * H + y];
   for (int i = lane; i < nh; i += 64) {
-    const int self = y * W + i;
+    const int self = (int)spk_slot(y, i, W, H);
     const int4 rec = *reinterpret_cast<const int4*>(R + self);   // parent, size, first, last
-    int r = rec.x;
-    if (r != self) {
-      r = uf_root_final<4>(P, r);
-      if (r != rec.x) P[4 * (size_t)self] = r;   // parents are final: point straight at the root so the apply kernel's lookup is one step
-    }
-    // every run adds its length to the root's (zero-initialised) size, unless the component is already known to exceed
-    // maxSpeckleSize (saturating: exact where it matters, no contention on large components)
+    if (rec.z >= 0 || rec.x == self) continue;                   // not an in-band root / a root nobody hooked
+    const int r = uf_root_final<4>(P, rec.x);
+    if (r != rec.x) P[4 * (size_t)self] = r;    // parents are final: point straight at the root so the apply kernel's lookup is one step
+    // What is large already stays a mark (idempotent); small sizes add up while the root is not known to be large. The check and
+    // the add are not one operation -- lanes that read the root together all add -- so the sum may overshoot by what the racers
+    // bring, at most maxsize each: with maxsize <= kSpkMaxSize (launch_speckle) that cannot reach the mark, let alone wrap.
     int* const sz = P + 4 * (size_t)r + 1;
-    if (__hip_atomic_load(sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(sz, rec.w - rec.z + 1);
+    if (rec.y > maxsize) __hip_atomic_fetch_max(sz, kSpkBig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (__hip_atomic_load(sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxsize) atomicAdd(sz, rec.y);
   }
 }
 
+// apply: a run whose component is large inside its own band stays (one load: the bulk); otherwise its in-band root decides, or --
+// if that root was hooked -- the final root.
 __global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __restrict__ disp, const SpkRun* __restrict__ runs,
                                                                   const int* __restrict__ nheads, int W, int H, int newval,
                                                                   int maxsize) {
   SPK_ROW_SETUP
   if (y >= H) return;
   int16_t* d = disp + plane_off + (size_t)y * W;
-  const SpkRun* const R = runs + plane_off;
+  const SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);
   const int nh = nheads[(size_t)blockIdx.y * H + y];
   for (int i = lane; i < nh; i += 64) {
-    const int self = y * W + i;
+    const int self = (int)spk_slot(y, i, W, H);
     const int4 rec = *reinterpret_cast<const int4*>(R + self);
-    const int root = rec.x == self ? self : uf_root_final<4>(&R->parent, rec.x);
-    const int size = root == self ? rec.y : R[root].size;
-    if (size <= maxsize)          // a speckle: its runs are at most maxsize long
-      for (int j = rec.z; j <= rec.w; j++) d[j] = (int16_t)newval;
+    if (rec.y > maxsize) continue;
+    int4 root = rec;
+    int rid = self;
+    if (rec.z >= 0) {                                   // not an in-band root: one step to it
+      rid = rec.x;
+      root = *reinterpret_cast<const int4*>(R + rid);
+      if (root.y > maxsize) continue;
+    }
+    if (root.x != rid) {                                // the in-band root was hooked: the final root's size counts
+      const int fin = uf_root_final<4>(&R->parent, root.x);
+      if (R[fin].size > maxsize) continue;
+    }
+    const int x0 = rec.z & 0x7fffffff;                 // a speckle: its runs are at most maxsize long
+    for (int j = x0; j <= rec.w; j++) d[j] = (int16_t)newval;
   }
 }
 
@@ -916,7 +1005,9 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
   // (read per call, ~0.1 us each: the GPU tests flip them between calls of one process to compare every variant with the CPU restatement)
   const int lists_env = env_switch("SBM_SPECKLE_LISTS", 1);
   const int band_env = env_switch("SBM_SPECKLE_BAND", -1);
-  const bool lists = nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 27) && lists_env != 0 && band_env != 0;
+  // (maxSpeckleSize beyond kSpkMaxSize: the row-walking kernels -- see the count kernel's size sums)
+  const bool lists = nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 27) && max_size <= kSpkMaxSize && lists_env != 0 &&
+                     band_env != 0;
   if (lists) {
     SpkRun* R = static_cast<SpkRun*>(runs);
     // 4 rows per wavefront once that still leaves ~6 000 band wavefronts (6 per SIMD), else 2: the walk of a band is a serial
@@ -931,7 +1022,7 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
     else
       hipLaunchKernelGGL(speckle_band_kernel<2>, bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, HS, g.W, g.H, g.filtered,
                          max_diff);
-    hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, R, seam, nseam, HS, g.W, g.H, G);
+    hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, R, seam, nseam, HS, g.W, g.H, G, max_size);
     hipLaunchKernelGGL(speckle_count_list_kernel, grid, dim3(256), 0, s, R, nheads, g.W, g.H, max_size);
     hipLaunchKernelGGL(speckle_apply_list_kernel, grid, dim3(256), 0, s, disp, R, nheads, g.W, g.H, g.filtered, max_size);
   } else {
