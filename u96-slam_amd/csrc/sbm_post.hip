@@ -560,18 +560,64 @@ __device__ __forceinline__ unsigned spk_seam_slot(unsigned band, unsigned i, uns
 constexpr int SPK_BG = 4;   // chunks loaded up front per row
 constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x10000000;
 
+// In-band bookkeeping of one wavefront, LOCAL mode: the band's runs -- at most kSpkCapR per row -- live in LDS while the band is
+// walked (parent, size, first, last per run; ids r * kSpkCapR + k), contacts inside the band are unioned there at once (LDS
+// atomics: ~100 ns a round trip instead of an L2's), and every record is written to memory ONCE, complete, when the band is
+// done: parent = in-band root, in-band size, first (+ root flag), last. Round 6, first version (GLOBAL mode, still the path of a
+// band with more than kSpkCapR runs in a row): records created and closed in memory during the walk, contacts buffered and
+// unioned by L2 atomics in flushes, two more sweeps of dependent L2 round trips for sizes and flags -- 8 us of flush + 18 us of
+// sweeps at the end of every wavefront of a 38 us kernel.
+#ifndef SPK_CAPR4
+#define SPK_CAPR4 128
+#endif
+#ifndef SPK_CAPR2
+#define SPK_CAPR2 256
+#endif
 template <int G>
-__global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
-                                                            int* __restrict__ nheads, unsigned* __restrict__ seam,
-                                                            int* __restrict__ nseam, int HS, int W, int H, int newval,
-                                                            int maxdiff) {
-  constexpr int SPK_BCAP = 128 * (G - 1) < 256 ? 256 : 128 * (G - 1);   // in-band contacts buffered per wavefront
-  __shared__ int2 contact_lds[4][SPK_BCAP];
+constexpr int kSpkCapR = G == 2 ? SPK_CAPR2 : SPK_CAPR4;
+template <int G>
+struct SpkLocal {
+  int par[G * kSpkCapR<G>];
+  unsigned short first[G * kSpkCapR<G>], last[G * kSpkCapR<G>];   // (the band walk serves up to 65 535 columns)
+  union {
+    unsigned contacts[G * kSpkCapR<G>];   // during the walk: in-band contacts (upper run | lower run << 16), unioned 64 at a time
+    int size[G * kSpkCapR<G>];            // after it: in-band size of the component, at its root
+  };
+};
+template <int G>
+union SpkBandLds {
+  SpkLocal<G> loc;
+  int2 contacts[128 * (G - 1) < 256 ? 256 : 128 * (G - 1)];   // GLOBAL mode: in-band contacts buffered per wavefront
+};
+
+__device__ __forceinline__ int lds_find(int* par, int i) {
+  for (;;) {
+    const int p = __hip_atomic_load(par + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (p == i) return i;
+    i = p;
+  }
+}
+__device__ __forceinline__ void lds_union(int* par, int a, int b) {
+  for (;;) {
+    a = lds_find(par, a);
+    b = lds_find(par, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int old = __hip_atomic_fetch_min(par + b, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old == b) return;
+    b = old;
+  }
+}
+
+// returns true when LOCAL mode ran out of record slots (nothing it wrote matters then: the caller walks the band again in GLOBAL mode)
+template <int G, bool LOCAL>
+__device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs, int* __restrict__ nheads,
+                                                  unsigned* __restrict__ seam, int* __restrict__ nseam, int HS, int W, int H, int newval,
+                                                  int maxdiff, SpkBandLds<G>* lds, const int band) {
+  constexpr int CAPR = kSpkCapR<G>;
+  constexpr int SPK_BCAP = 128 * (G - 1) < 256 ? 256 : 128 * (G - 1);
   const int lane = threadIdx.x & 63;
   const int nbands = (H + G - 1) / G;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: keeps row pointers and counters in SGPRs
-  const int band = blockIdx.x * 4 + wave;
-  if (band >= nbands) return;
   constexpr int cs = 0;
   const int ce = W;
   const int y0 = band * G;
@@ -579,15 +625,25 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
   const int16_t* d = disp + plane_off;
   SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);   // this pair's records (dense block + plane)
   int* const P = &R->parent;                                   // parent of slot i: P[4 i]
-  int2* const list = contact_lds[wave];
+  int2* const list = lds->contacts;
+  SpkLocal<G>& loc = lds->loc;
   unsigned* const sl = seam + (size_t)blockIdx.y * ((size_t)nbands * kSpkDenseSeam + (size_t)nbands * HS);   // this pair's seam lists
   int count = 0, nsm = 0;   // uniform: buffered in-band contacts, seam contacts listed so far
   auto flush = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // record stores of this wavefront have left before the unions start
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < count; i += 64) {
-      const int2 c = list[i];
-      uf_union<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, c.x, c.y);
+    if constexpr (LOCAL) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < count; i += 64) {
+        const unsigned c = loc.contacts[i];
+        lds_union(loc.par, (int)(c & 0xffffu), (int)(c >> 16));
+      }
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // record stores of this wavefront have left before the unions start
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < count; i += 64) {
+        const int2 c = list[i];
+        uf_union<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, c.x, c.y);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     count = 0;
@@ -682,6 +738,23 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
         auto run_of = [&](int r) -> int {   // index of the lane's run within its row; valid lanes only
           return nh[r] - 1 + lanes_below(head[r]) + (int)((head[r] >> lane) & 1ull);
         };
+        if constexpr (LOCAL) {
+          // out of slots? (uniform) -> the band is walked again in GLOBAL mode
+          bool full = false;
+#pragma unroll
+          for (int r = 0; r < G; r++) full |= nh[r] + __popcll(head[r]) > CAPR;
+          if (full) return true;
+          // the heads of this chunk open their records (the contacts that name them are unioned later, in batches)
+#pragma unroll
+          for (int r = 0; r < G; r++) {
+            const unsigned long long hm = head[r];
+            if (hm && lane_in(hm)) {
+              const int id = r * CAPR + nh[r] + lanes_below(hm);
+              loc.par[id] = id;
+              loc.first[id] = (unsigned short)(cb + lane);
+            }
+          }
+        }
 #pragma unroll
         for (int r = 1; r <= G; r++) {
           const unsigned long long cdm = __ballot(tv[r] <= tm);
@@ -692,8 +765,12 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
             if (lane_in(fm)) {
               const int k = lanes_below(fm);
               const int ku = run_of(r - 1), kd = run_of(r);
-              if (r < G) list[count + k] = make_int2((int)spk_slot(y0 + r - 1, ku, W, H), (int)spk_slot(y0 + r, kd, W, H));
-              else *at32(sl, spk_seam_slot(band, (unsigned)(nsm + k), nbands, HS)) = (unsigned)ku | ((unsigned)kd << 16);
+              if (r < G) {
+                if constexpr (LOCAL) loc.contacts[count + k] = (unsigned)((r - 1) * CAPR + ku) | ((unsigned)(r * CAPR + kd) << 16);
+                else list[count + k] = make_int2((int)spk_slot(y0 + r - 1, ku, W, H), (int)spk_slot(y0 + r, kd, W, H));
+              } else {
+                *at32(sl, spk_seam_slot(band, (unsigned)(nsm + k), nbands, HS)) = (unsigned)ku | ((unsigned)kd << 16);
+              }
             }
             if (r < G) count += __popcll(fm);
             else nsm += __popcll(fm);
@@ -705,24 +782,30 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
         for (int r = 0; r < G; r++) {
           const unsigned long long hm = head[r];
           const unsigned long long em = __ballot(pv[r] < kSpkFarMin) & (hm | ~vm[r]);
-          if (hm) {
-            if (lane_in(hm)) {
-              const unsigned self = spk_slot(y0 + r, (unsigned)(nh[r] + lanes_below(hm)), W, H);
-              int* q = &at32(R, self)->parent;
-              // parent = self, size = 0 (accumulated by the count kernel), first column; the last column follows when the run ends
-              __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              q[1] = 0;
-              q[2] = cb + lane;
+          if constexpr (!LOCAL) {
+            if (hm) {
+              if (lane_in(hm)) {
+                const unsigned self = spk_slot(y0 + r, (unsigned)(nh[r] + lanes_below(hm)), W, H);
+                int* q = &at32(R, self)->parent;
+                // parent = self, size = 0 (summed in the last phase), first column; the last column follows when the run ends
+                __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                q[1] = 0;
+                q[2] = cb + lane;
+              }
             }
           }
           if (em) {
-            if (lane_in(em)) at32(R, spk_slot(y0 + r, (unsigned)(ne[r] + lanes_below(em)), W, H))->last = cb + lane - 1;
+            if (lane_in(em)) {
+              const int k = ne[r] + lanes_below(em);
+              if constexpr (LOCAL) loc.last[r * CAPR + k] = (unsigned short)(cb + lane - 1);
+              else at32(R, spk_slot(y0 + r, (unsigned)k, W, H))->last = cb + lane - 1;
+            }
             ne[r] += __popcll(em);
           }
         }
 #pragma unroll
         for (int r = 0; r <= G; r++) nh[r] += __popcll(head[r]);
-        if (count > SPK_BCAP - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
+        if (count > (LOCAL ? G * CAPR : SPK_BCAP) - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
       }
       prev_empty = !quiet && empty;
 #pragma unroll
@@ -741,7 +824,10 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
     for (int r = 0; r < G; r++) {
       const int y = y0 + r;
       if (y < H) {
-        if ((tail >> r) & 1u) at32(R, spk_slot(y0 + r, (unsigned)ne[r], W, H))->last = ce - 1;
+        if ((tail >> r) & 1u) {
+          if constexpr (LOCAL) loc.last[r * CAPR + ne[r]] = (unsigned short)(ce - 1);
+          else at32(R, spk_slot(y0 + r, (unsigned)ne[r], W, H))->last = ce - 1;
+        }
         nheads[(size_t)blockIdx.y * H + y] = nh[r];
       }
     }
@@ -760,38 +846,85 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
     int nhmax = nh[0];
 #pragma unroll
     for (int r = 1; r < G; r++) nhmax = max(nhmax, nh[r]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the records' last stores (run ends) have left
-    __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < nhmax; base += LPR) {
-      const int k = base + li;
-      if (k < nhq) {
-        const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
-        SpkRun* const rec = at32(R, self);
-        const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int lst = __hip_atomic_load(&rec->last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int root = uf_find<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, (int)self);
-        if (root != (int)self) __hip_atomic_store(&rec->parent, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // compressed: one step to the in-band root
-        __hip_atomic_fetch_add(&at32(R, (unsigned)root)->size, lst - fst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (LOCAL) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < G * CAPR; i += 64) loc.size[i + lane] = 0;   // (the contact list is done with)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int base = 0; base < nhmax; base += LPR) {
+        const int k = base + li;
+        if (k < nhq) {
+          const int id = q * CAPR + k;
+          const int root = lds_find(loc.par, id);
+          loc.par[id] = root;      // (a node's parent only ever moves towards its root: concurrent finds stay right)
+          __hip_atomic_fetch_add(&loc.size[root], (int)loc.last[id] - (int)loc.first[id] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);                          // the size sums are complete
-    __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < nhmax; base += LPR) {
-      const int k = base + li;
-      if (k < nhq) {
-        const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
-        SpkRun* const rec = at32(R, self);
-        const int root = __hip_atomic_load(&rec->parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (root == (int)self) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int base = 0; base < nhmax; base += LPR) {
+        const int k = base + li;
+        if (k < nhq) {
+          const int id = q * CAPR + k;
+          const int root = loc.par[id];
+          const int rq = root / CAPR, rk = root - rq * CAPR;
+          const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
+          // the record, complete, in one store: parent = the in-band root's slot, the component's in-band size, first (+ root flag), last
+          *reinterpret_cast<int4*>(at32(R, self)) = make_int4((int)spk_slot(y0 + rq, (unsigned)rk, W, H), loc.size[root],
+                                                              (int)loc.first[id] | (root == id ? kSpkRootFlag : 0), (int)loc.last[id]);
+        }
+      }
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the records' last stores (run ends) have left
+      __builtin_amdgcn_wave_barrier();
+      for (int base = 0; base < nhmax; base += LPR) {
+        const int k = base + li;
+        if (k < nhq) {
+          const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
+          SpkRun* const rec = at32(R, self);
           const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          rec->first = fst | kSpkRootFlag;
-        } else {
-          rec->size = __hip_atomic_load(&at32(R, (unsigned)root)->size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int lst = __hip_atomic_load(&rec->last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int root = uf_find<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, (int)self);
+          if (root != (int)self) __hip_atomic_store(&rec->parent, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // compressed: one step to the in-band root
+          __hip_atomic_fetch_add(&at32(R, (unsigned)root)->size, lst - fst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);                          // the size sums are complete
+      __builtin_amdgcn_wave_barrier();
+      for (int base = 0; base < nhmax; base += LPR) {
+        const int k = base + li;
+        if (k < nhq) {
+          const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
+          SpkRun* const rec = at32(R, self);
+          const int root = __hip_atomic_load(&rec->parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (root == (int)self) {
+            const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rec->first = fst | kSpkRootFlag;
+          } else {
+            rec->size = __hip_atomic_load(&at32(R, (unsigned)root)->size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
     }
   }
+  return false;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
+                                                            int* __restrict__ nheads, unsigned* __restrict__ seam,
+                                                            int* __restrict__ nseam, int HS, int W, int H, int newval,
+                                                            int maxdiff) {
+  __shared__ SpkBandLds<G> band_lds[4];
+  const int nbands = (H + G - 1) / G;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: keeps row pointers and counters in SGPRs
+  const int band = blockIdx.x * 4 + wave;
+  if (band >= nbands) return;
+  if (speckle_band_walk<G, true>(disp, runs, nheads, seam, nseam, HS, W, H, newval, maxdiff, &band_lds[wave], band))
+    speckle_band_walk<G, false>(disp, runs, nheads, seam, nseam, HS, W, H, newval, maxdiff, &band_lds[wave], band);
 }
 
 // Seam contacts of the band walk: one wavefront per band, 64 contacts at a time. Both records of a contact are loaded at once and
