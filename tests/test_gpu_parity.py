@@ -689,17 +689,19 @@ def test_border_columns_inside_the_interior_launch(pkg, oracle, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("band", ["0", "2", "4"])
+@pytest.mark.parametrize("band,seg", [("0", "0"), ("2", "1"), ("2", "2"), ("2", "4"), ("4", "1"), ("4", "2"), ("4", "4"), ("-1", "0")])
 @pytest.mark.parametrize("shape", [(37, 70, 1), (130, 300, 2), (64, 257, 3), (375, 1242, 2), (201, 515, 40), (50, 64, 2), (61, 128, 3),
-                                   (33, 1280, 1)])
-def test_speckle_band_walk_variants(pkg, oracle, band, shape, monkeypatch):
-    """The speckle filter's band walk (runs + merge of 2/4 rows in one wavefront, seam contacts unioned by a second
-    kernel) against the oracle: heights that are not multiples of the band, widths that are not multiples of a chunk or a
-    load group and widths that are (a run that reaches the last column then ends behind the walk), components that cross
-    many seams, and a batch large enough for every automatic band choice."""
+                                   (33, 1280, 1), (45, 320, 2), (30, 321, 2)])
+def test_speckle_band_walk_variants(pkg, oracle, band, seg, shape, monkeypatch):
+    """The speckle filter's band walk (runs + merge of 2/4 rows by the wavefronts of a workgroup, one column segment each;
+    seam contacts unioned by a second kernel) against the oracle: every band height and segment count (and the automatic
+    choice), heights that are not multiples of the band, widths that are not multiples of a chunk or a load group and widths
+    that are (a run that reaches a segment's last column then ends behind the walk), widths that leave the last segment
+    empty, components that cross many seams and segment edges, and a batch large enough for every automatic choice."""
     from u96_slam_amd import synth
 
     monkeypatch.setenv("SBM_SPECKLE_BAND", band)
+    monkeypatch.setenv("SBM_SPECKLE_SEG", seg)
     H, W, n = shape
     nd = 32 if W < 400 else 64
     L, R = synth.make_batch(11, n, W, H, nd)
@@ -720,12 +722,14 @@ def test_speckle_band_walk_variants(pkg, oracle, band, shape, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seg", ["1", "4"])
 @pytest.mark.parametrize("lists,band", [("1", "-1"), ("1", "0"), ("1", "2"), ("1", "4"), ("0", "-1")])
-def test_speckle_with_one_run_per_pixel(pkg, oracle, lists, band, monkeypatch):
+def test_speckle_with_one_run_per_pixel(pkg, oracle, lists, band, seg, monkeypatch):
     """speckleRange 0 on a noisy map: adjacent valid pixels rarely agree, so nearly every pixel is its own run -- the
     worst case for the compact run-head lists of the speckle filter (up to W heads per row), in every kernel variant."""
     monkeypatch.setenv("SBM_SPECKLE_LISTS", lists)
     monkeypatch.setenv("SBM_SPECKLE_BAND", band)   # band walk (2/4 rows per wavefront), 0 = separate runs + merge kernels
+    monkeypatch.setenv("SBM_SPECKLE_SEG", seg)     # column segments per band
     rng = np.random.default_rng(42)
     L = rng.integers(0, 256, (3, 96, 400), dtype=np.uint8)      # no correlation between the images: disparities are noise
     R = rng.integers(0, 256, (3, 96, 400), dtype=np.uint8)

@@ -243,7 +243,7 @@ static size_t scratch_bytes(const sbm_handle* h) {
   const size_t npix = (size_t)h->cap_n * h->cap_W * h->cap_H, plane = (size_t)h->cap_n * h->cap_pitch * h->cap_H;
   size_t b = 2 * plane + npix * 2;
   if (h->cost) b += npix * 4;
-  if (h->spk_runs) b += npix * 18 + (size_t)h->cap_n * h->cap_H * 6;   // run records, seam lists, run / contact counts
+  if (h->spk_runs) b += (size_t)h->cap_n * h->cap_H * (16 * ((size_t)h->cap_W + kSpkRecordPad) + 2 * ((size_t)h->cap_W + kSpkSeamPad) + 24);   // run records, seam lists, run / contact counts
   if (h->vsum) b += 2 * npix * sizeof(uint16_t);
   b += (size_t)h->st_n * h->st_W * h->st_H * 4 + h->pin_bytes;
   b += (size_t)h->fq_n * h->fq_W * h->fq_H * 8;
@@ -436,12 +436,12 @@ static int ensure_scratch(sbm_handle* h, int n, int W, int H, int pitch, bool ne
   if (need_speckle && !h->spk_nseam) {   // keyed on the LAST buffer of the set: an attempt that failed half way is redone
     hipFree(h->spk_runs); hipFree(h->spk_nheads); hipFree(h->spk_seam);
     h->spk_runs = nullptr; h->spk_nheads = nullptr; h->spk_seam = nullptr;
-    // run records: per pair a dense block (16 per row) + the per-pixel plane behind it (sbm_post.hip: spk_slot)
-    HIPCHK(h, hipMalloc(&h->spk_runs, (npix + (size_t)h->cap_n * H * 16) * 16));
-    HIPCHK(h, hipMalloc((void**)&h->spk_nheads, (size_t)h->cap_n * H * sizeof(int32_t)));
+    // sizes: launch_speckle (sbm_common.h)
+    HIPCHK(h, hipMalloc(&h->spk_runs, (size_t)h->cap_n * H * ((size_t)W + kSpkRecordPad) * 16));
+    HIPCHK(h, hipMalloc((void**)&h->spk_nheads, (size_t)h->cap_n * H * kSpkMaxSeg * sizeof(int32_t)));
     const size_t seams = (size_t)h->cap_n * ((H + 1) / 2);
-    HIPCHK(h, hipMalloc((void**)&h->spk_seam, seams * ((size_t)W + 32) * sizeof(uint32_t)));   // (+ the dense block: spk_seam_slot)
-    HIPCHK(h, hipMalloc((void**)&h->spk_nseam, seams * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc((void**)&h->spk_seam, seams * ((size_t)W + kSpkSeamPad) * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc((void**)&h->spk_nseam, seams * kSpkMaxSeg * sizeof(int32_t)));
   }
   return SBM_OK;
 }

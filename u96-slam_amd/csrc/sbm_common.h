@@ -101,9 +101,12 @@ hipError_t launch_sad_fast(const uint8_t* pf_l, const uint8_t* pf_r, int16_t* di
 hipError_t launch_lrcheck(const int16_t* disp_pre, const int32_t* cost, int16_t* disp_out, const Geom& g,
                           int disp12_max_diff, hipStream_t s);
 
-// cv filterSpeckles as parallel connected components (union-find). runs: 16 bytes per pixel of scratch (run records of the
-// band walk, or the per-pixel labels + sizes of the row-walking kernels); nheads: n*H int32 (runs per row; may be null ->
-// row-walking kernels); seam: n*ceil(H/2)*W uint32, nseam: n*ceil(H/2) int32 (contacts across band seams).
+// cv filterSpeckles as parallel connected components (union-find). Scratch, for n pairs of W x H (the band walk cuts a row into
+// up to kSpkMaxSeg column segments with books of their own, hence the padding): runs: 16 * n * H * (W + kSpkRecordPad) bytes (run
+// records of the band walk, or the per-pixel labels + sizes of the row-walking kernels); nheads: n * H * kSpkMaxSeg int32 (runs
+// per row and segment; null -> row-walking kernels); seam: n * ceil(H/2) * (W + kSpkSeamPad) uint32, nseam: n * ceil(H/2) *
+// kSpkMaxSeg int32 (contacts across band seams).
+constexpr int kSpkMaxSeg = 4, kSpkRecordPad = 288, kSpkSeamPad = 512;
 hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* seam, int32_t* nseam, const Geom& g, int max_size,
                           int max_diff, hipStream_t s);
 

@@ -550,9 +550,10 @@ constexpr int kSpkRootFlag = (int)0x80000000u, kSpkBig = 0x40000000, kSpkMaxSize
 // spent ~10 us each on 24 000 cold TLB entries (64 KITTI pairs). So the first kSpkDense runs of a row live in a dense block (256
 // bytes per row: 6 MB for that batch), only the runs beyond them in the per-pixel plane behind it. Same for the seam lists: the
 // first kSpkDenseSeam contacts of a band's seam in a dense block, the rest in the band's W slots.
-constexpr unsigned kSpkDense = 16, kSpkDenseSeam = 32;
-__device__ __forceinline__ unsigned spk_slot(unsigned y, unsigned k, unsigned W, unsigned H) {
-  return k < kSpkDense ? y * kSpkDense + k : H * kSpkDense + y * W + k;
+constexpr unsigned kSpkDenseSeam = 32;
+constexpr int kSpkSeg4 = 1000, kSpkSeg2 = 2500;   // launches of fewer pairs of rows than this are cut into 4 / 2 column segments (launch_speckle)
+__device__ __forceinline__ unsigned spk_slot(unsigned y, unsigned k, unsigned W, unsigned H, unsigned dense) {
+  return k < dense ? y * dense + k : H * dense + y * W + k;
 }
 __device__ __forceinline__ unsigned spk_seam_slot(unsigned band, unsigned i, unsigned nbands, unsigned HS) {
   return i < kSpkDenseSeam ? band * kSpkDenseSeam + i : nbands * kSpkDenseSeam + band * HS + i;
@@ -560,13 +561,16 @@ __device__ __forceinline__ unsigned spk_seam_slot(unsigned band, unsigned i, uns
 constexpr int SPK_BG = 4;   // chunks loaded up front per row
 constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x10000000;
 
-// In-band bookkeeping of one wavefront, LOCAL mode: the band's runs -- at most kSpkCapR per row -- live in LDS while the band is
-// walked (parent, size, first, last per run; ids r * kSpkCapR + k), contacts inside the band are unioned there at once (LDS
-// atomics: ~100 ns a round trip instead of an L2's), and every record is written to memory ONCE, complete, when the band is
-// done: parent = in-band root, in-band size, first (+ root flag), last. Round 6, first version (GLOBAL mode, still the path of a
-// band with more than kSpkCapR runs in a row): records created and closed in memory during the walk, contacts buffered and
-// unioned by L2 atomics in flushes, two more sweeps of dependent L2 round trips for sizes and flags -- 8 us of flush + 18 us of
-// sweeps at the end of every wavefront of a 38 us kernel.
+// In-band bookkeeping of the band walk. A band (G rows) is walked by S wavefronts of one workgroup, one column segment each
+// (S = 1, 2 or 4: launch_speckle); for the books a segment of a row is a row of its own ("virtual row" y * S + segment: its own
+// run numbering, record slots, run count and seam list), so the segments walk independently and only the runs that cross a
+// segment boundary need joining afterwards -- in LDS, behind a workgroup barrier.
+// LOCAL mode: the runs of the walk -- at most kSpkCapR per row and segment -- live in LDS while the band is walked (parent, first,
+// last per run; id = wavefront * N + row * kSpkCapR + k), contacts inside the band are listed there and unioned 64 at a time
+// (LDS atomics: ~100 ns a round trip instead of an L2's), and every record is written to memory ONCE, complete, when the band is
+// done: parent = in-band root, in-band size, first (+ root flag), last. GLOBAL mode (first version of round 6, still the path of
+// a band with more than kSpkCapR runs in some row of some segment): records created and closed in memory during the walk,
+// contacts unioned by L2 atomics, two more sweeps of dependent L2 round trips for sizes and flags.
 #ifndef SPK_CAPR4
 #define SPK_CAPR4 128
 #endif
@@ -576,19 +580,17 @@ constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x100
 template <int G>
 constexpr int kSpkCapR = G == 2 ? SPK_CAPR2 : SPK_CAPR4;
 template <int G>
-struct SpkLocal {
-  int par[G * kSpkCapR<G>];
-  unsigned short first[G * kSpkCapR<G>], last[G * kSpkCapR<G>];   // (the band walk serves up to 65 535 columns)
-  union {
-    unsigned contacts[G * kSpkCapR<G>];   // during the walk: in-band contacts (upper run | lower run << 16), unioned 64 at a time
-    int size[G * kSpkCapR<G>];            // after it: in-band size of the component, at its root
-  };
+struct SpkWgLds {
+  static constexpr int N = G * kSpkCapR<G>;   // run ids of one wavefront
+  int par[4 * N];
+  unsigned short first[4 * N], last[4 * N];   // (the band walk serves up to 65 535 columns)
+  // walk: the wavefront's own N entries are its contact list (LOCAL: upper id | lower id << 16; GLOBAL: N / 2 pairs of record
+  // slots); last phase: in-band size of a component, at its root
+  unsigned cs[4 * N];
+  int nh[4][G];    // runs per owned row of every wavefront (the segment to the right joins its first run to this one's last)
+  int ovf[4];      // LOCAL mode ran out of run ids
 };
-template <int G>
-union SpkBandLds {
-  SpkLocal<G> loc;
-  int2 contacts[128 * (G - 1) < 256 ? 256 : 128 * (G - 1)];   // GLOBAL mode: in-band contacts buffered per wavefront
-};
+static_assert(SpkWgLds<2>::N / 2 > 64 && SpkWgLds<4>::N / 2 > 64 * 3 && 4 * SpkWgLds<2>::N <= 65536 && 4 * SpkWgLds<4>::N <= 65536, "");
 
 __device__ __forceinline__ int lds_find(int* par, int i) {
   for (;;) {
@@ -609,33 +611,42 @@ __device__ __forceinline__ void lds_union(int* par, int a, int b) {
   }
 }
 
-// returns true when LOCAL mode ran out of record slots (nothing it wrote matters then: the caller walks the band again in GLOBAL mode)
-template <int G, bool LOCAL>
-__device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs, int* __restrict__ nheads,
-                                                  unsigned* __restrict__ seam, int* __restrict__ nseam, int HS, int W, int H, int newval,
-                                                  int maxdiff, SpkBandLds<G>* lds, const int band) {
+// Where everything of a pair lives: S column segments of SW columns, HV = H * S virtual rows, nbands * S virtual bands.
+template <int S>
+struct SpkLayout {
+  static constexpr int D = S == 1 ? 16 : 8;   // records of a virtual row in the dense block
+  int SW;
+  __host__ __device__ size_t records(int H) const { return (size_t)H * S * ((size_t)D + SW); }
+  __host__ __device__ size_t seam_slots(int nbands) const { return (size_t)nbands * S * ((size_t)kSpkDenseSeam + SW); }
+};
+
+// The walk of one column segment [cs, ce) of one band. Returns true when LOCAL mode ran out of run ids (nothing it wrote matters
+// then: the band is walked again in GLOBAL mode). nh[r]: runs of row r in this segment; nsm: seam contacts listed.
+template <int G, int S, bool LOCAL>
+__device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d, SpkRun* __restrict__ R, unsigned* __restrict__ sl,
+                                                  const SpkLayout<S> lay, int W, int H, int newval, int maxdiff, SpkWgLds<G>& lds,
+                                                  const int wave, const int band, const int seg, const int cs, const int ce,
+                                                  int (&nh)[G + 1], int& nsm) {
   constexpr int CAPR = kSpkCapR<G>;
-  constexpr int SPK_BCAP = 128 * (G - 1) < 256 ? 256 : 128 * (G - 1);
+  constexpr int N = SpkWgLds<G>::N;
   const int lane = threadIdx.x & 63;
-  const int nbands = (H + G - 1) / G;
-  constexpr int cs = 0;
-  const int ce = W;
+  const int nbandsv = ((H + G - 1) / G) * S, bandv = band * S + seg;
+  const int SW = lay.SW;
   const int y0 = band * G;
-  const size_t plane_off = (size_t)blockIdx.y * W * H;
-  const int16_t* d = disp + plane_off;
-  SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);   // this pair's records (dense block + plane)
+  const int idbase = wave * N;
   int* const P = &R->parent;                                   // parent of slot i: P[4 i]
-  int2* const list = lds->contacts;
-  SpkLocal<G>& loc = lds->loc;
-  unsigned* const sl = seam + (size_t)blockIdx.y * ((size_t)nbands * kSpkDenseSeam + (size_t)nbands * HS);   // this pair's seam lists
-  int count = 0, nsm = 0;   // uniform: buffered in-band contacts, seam contacts listed so far
+  unsigned* const clist = lds.cs + idbase;
+  int2* const list = reinterpret_cast<int2*>(clist);
+  auto slot = [&](int r, int k) -> unsigned { return spk_slot((unsigned)((y0 + r) * S + seg), (unsigned)k, (unsigned)SW, (unsigned)(H * S), (unsigned)lay.D); };
+  int count = 0;   // uniform: buffered in-band contacts
+  nsm = 0;
   auto flush = [&]() {
     if constexpr (LOCAL) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       for (int i = lane; i < count; i += 64) {
-        const unsigned c = loc.contacts[i];
-        lds_union(loc.par, (int)(c & 0xffffu), (int)(c >> 16));
+        const unsigned c = clist[i];
+        lds_union(lds.par, (int)(c & 0xffffu), (int)(c >> 16));
       }
     } else {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // record stores of this wavefront have left before the unions start
@@ -652,7 +663,7 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
   // substitutes of invalid pixels: rows of even / odd parity (bands start on even rows: G is even)
   const int far_e = kSpkFar + ((lane & 1) ? kSpkFarStep : 0), far_o = kSpkFar + ((lane & 1) ? 0 : kSpkFarStep);
 
-  int nh[G + 1], ne[G];   // uniform: runs started (owned rows and the look-ahead row) / ended so far
+  int ne[G];   // uniform: runs ended so far (nh: runs started, owned rows and the look-ahead row)
 #pragma unroll
   for (int r = 0; r <= G; r++) nh[r] = 0;
 #pragma unroll
@@ -675,7 +686,7 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
     const int vo = 2 * (cb0 + lane);
 #pragma unroll
     for (int r = 0; r <= G; r++) {
-      const int so = 2 * min(y0 + r, H - 1) * W;
+      const int so = 2 * min(y0 + r, H - 1) * W;   // (columns beyond the segment are loaded and not used)
 #pragma unroll
       for (int g = 0; g < SPK_BG; g++) vn[r][g] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rs_d, vo + 128 * g, so, 0);
     }
@@ -749,9 +760,9 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
           for (int r = 0; r < G; r++) {
             const unsigned long long hm = head[r];
             if (hm && lane_in(hm)) {
-              const int id = r * CAPR + nh[r] + lanes_below(hm);
-              loc.par[id] = id;
-              loc.first[id] = (unsigned short)(cb + lane);
+              const int id = idbase + r * CAPR + nh[r] + lanes_below(hm);
+              lds.par[id] = id;
+              lds.first[id] = (unsigned short)(cb + lane);
             }
           }
         }
@@ -766,10 +777,10 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
               const int k = lanes_below(fm);
               const int ku = run_of(r - 1), kd = run_of(r);
               if (r < G) {
-                if constexpr (LOCAL) loc.contacts[count + k] = (unsigned)((r - 1) * CAPR + ku) | ((unsigned)(r * CAPR + kd) << 16);
-                else list[count + k] = make_int2((int)spk_slot(y0 + r - 1, ku, W, H), (int)spk_slot(y0 + r, kd, W, H));
+                if constexpr (LOCAL) clist[count + k] = (unsigned)(idbase + (r - 1) * CAPR + ku) | ((unsigned)(idbase + r * CAPR + kd) << 16);
+                else list[count + k] = make_int2((int)slot(r - 1, ku), (int)slot(r, kd));
               } else {
-                *at32(sl, spk_seam_slot(band, (unsigned)(nsm + k), nbands, HS)) = (unsigned)ku | ((unsigned)kd << 16);
+                *at32(sl, spk_seam_slot(bandv, (unsigned)(nsm + k), nbandsv, SW)) = (unsigned)ku | ((unsigned)kd << 16);
               }
             }
             if (r < G) count += __popcll(fm);
@@ -785,7 +796,7 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
           if constexpr (!LOCAL) {
             if (hm) {
               if (lane_in(hm)) {
-                const unsigned self = spk_slot(y0 + r, (unsigned)(nh[r] + lanes_below(hm)), W, H);
+                const unsigned self = slot(r, nh[r] + lanes_below(hm));
                 int* q = &at32(R, self)->parent;
                 // parent = self, size = 0 (summed in the last phase), first column; the last column follows when the run ends
                 __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -797,15 +808,15 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
           if (em) {
             if (lane_in(em)) {
               const int k = ne[r] + lanes_below(em);
-              if constexpr (LOCAL) loc.last[r * CAPR + k] = (unsigned short)(cb + lane - 1);
-              else at32(R, spk_slot(y0 + r, (unsigned)k, W, H))->last = cb + lane - 1;
+              if constexpr (LOCAL) lds.last[idbase + r * CAPR + k] = (unsigned short)(cb + lane - 1);
+              else at32(R, slot(r, k))->last = cb + lane - 1;
             }
             ne[r] += __popcll(em);
           }
         }
 #pragma unroll
         for (int r = 0; r <= G; r++) nh[r] += __popcll(head[r]);
-        if (count > (LOCAL ? G * CAPR : SPK_BCAP) - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
+        if (count > (LOCAL ? N : N / 2) - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
       }
       prev_empty = !quiet && empty;
 #pragma unroll
@@ -813,7 +824,7 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
       mvp = mv;
     }
   }
-  // runs that reach the row's last column end there (a chunk-aligned row end has no boundary lane behind it)
+  // runs that reach the segment's last column end there (a chunk-aligned end has no boundary lane behind it)
   unsigned tail = 0u;
   if (((ce - cs) & 63) == 0) {
 #pragma unroll
@@ -822,109 +833,167 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ di
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < G; r++) {
-      const int y = y0 + r;
-      if (y < H) {
-        if ((tail >> r) & 1u) {
-          if constexpr (LOCAL) loc.last[r * CAPR + ne[r]] = (unsigned short)(ce - 1);
-          else at32(R, spk_slot(y0 + r, (unsigned)ne[r], W, H))->last = ce - 1;
-        }
-        nheads[(size_t)blockIdx.y * H + y] = nh[r];
+      if (y0 + r < H && ((tail >> r) & 1u)) {
+        if constexpr (LOCAL) lds.last[idbase + r * CAPR + ne[r]] = (unsigned short)(ce - 1);
+        else at32(R, slot(r, ne[r]))->last = ce - 1;
       }
     }
-    nseam[(size_t)blockIdx.y * nbands + band] = nsm;
   }
   if (count) flush();
-  // ---- last phase: the band's components are final INSIDE the band. Every run learns the in-band size of its component, every
-  // in-band root is flagged: the seam / count / apply kernels then settle the bulk of the runs from the run's own record.
-  // Lanes = (row of the band, run of that row), 64 / G runs of every row at a time; two sweeps with the band's size sums between.
-  {
-    constexpr int LPR = 64 / G;                      // lanes per row
-    const int q = lane / LPR, li = lane - q * LPR;
-    int nhq = 0;
-#pragma unroll
-    for (int r = 0; r < G; r++) nhq = q == r ? nh[r] : nhq;
-    int nhmax = nh[0];
-#pragma unroll
-    for (int r = 1; r < G; r++) nhmax = max(nhmax, nh[r]);
-    if constexpr (LOCAL) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < G * CAPR; i += 64) loc.size[i + lane] = 0;   // (the contact list is done with)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int base = 0; base < nhmax; base += LPR) {
-        const int k = base + li;
-        if (k < nhq) {
-          const int id = q * CAPR + k;
-          const int root = lds_find(loc.par, id);
-          loc.par[id] = root;      // (a node's parent only ever moves towards its root: concurrent finds stay right)
-          __hip_atomic_fetch_add(&loc.size[root], (int)loc.last[id] - (int)loc.first[id] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int base = 0; base < nhmax; base += LPR) {
-        const int k = base + li;
-        if (k < nhq) {
-          const int id = q * CAPR + k;
-          const int root = loc.par[id];
-          const int rq = root / CAPR, rk = root - rq * CAPR;
-          const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
-          // the record, complete, in one store: parent = the in-band root's slot, the component's in-band size, first (+ root flag), last
-          *reinterpret_cast<int4*>(at32(R, self)) = make_int4((int)spk_slot(y0 + rq, (unsigned)rk, W, H), loc.size[root],
-                                                              (int)loc.first[id] | (root == id ? kSpkRootFlag : 0), (int)loc.last[id]);
-        }
-      }
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the records' last stores (run ends) have left
-      __builtin_amdgcn_wave_barrier();
-      for (int base = 0; base < nhmax; base += LPR) {
-        const int k = base + li;
-        if (k < nhq) {
-          const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
-          SpkRun* const rec = at32(R, self);
-          const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const int lst = __hip_atomic_load(&rec->last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const int root = uf_find<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, (int)self);
-          if (root != (int)self) __hip_atomic_store(&rec->parent, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // compressed: one step to the in-band root
-          __hip_atomic_fetch_add(&at32(R, (unsigned)root)->size, lst - fst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_s_waitcnt(0);                          // the size sums are complete
-      __builtin_amdgcn_wave_barrier();
-      for (int base = 0; base < nhmax; base += LPR) {
-        const int k = base + li;
-        if (k < nhq) {
-          const unsigned self = spk_slot(y0 + q, (unsigned)k, W, H);
-          SpkRun* const rec = at32(R, self);
-          const int root = __hip_atomic_load(&rec->parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (root == (int)self) {
-            const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rec->first = fst | kSpkRootFlag;
-          } else {
-            rec->size = __hip_atomic_load(&at32(R, (unsigned)root)->size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
-      }
-    }
-  }
   return false;
 }
 
-template <int G>
+// grid: (ceil(nbands * S / 4), n), block 256 = 4 wavefronts = 4 / S bands x S column segments
+template <int G, int S>
 __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
                                                             int* __restrict__ nheads, unsigned* __restrict__ seam,
-                                                            int* __restrict__ nseam, int HS, int W, int H, int newval,
+                                                            int* __restrict__ nseam, const SpkLayout<S> lay, int W, int H, int newval,
                                                             int maxdiff) {
-  __shared__ SpkBandLds<G> band_lds[4];
+  constexpr int CAPR = kSpkCapR<G>;
+  constexpr int N = SpkWgLds<G>::N;
+  __shared__ SpkWgLds<G> lds;
+  const int lane = threadIdx.x & 63;
+  const int SW = lay.SW;
+  // S = 1: the four wavefronts are four bands that have nothing to do with each other -- no workgroup barriers
+  auto sync = [&](bool stores) {
+    if constexpr (S > 1) {
+      __syncthreads();
+    } else {
+      if (stores) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wavefront's record stores have left)
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
   const int nbands = (H + G - 1) / G;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: keeps row pointers and counters in SGPRs
-  const int band = blockIdx.x * 4 + wave;
-  if (band >= nbands) return;
-  if (speckle_band_walk<G, true>(disp, runs, nheads, seam, nseam, HS, W, H, newval, maxdiff, &band_lds[wave], band))
-    speckle_band_walk<G, false>(disp, runs, nheads, seam, nseam, HS, W, H, newval, maxdiff, &band_lds[wave], band);
+  const int bl = wave / S, seg = wave - bl * S;
+  const int band = blockIdx.x * (4 / S) + bl;
+  const int y0 = band * G;
+  const int cs = seg * SW, ce = min(W, cs + SW);
+  const bool walks = band < nbands && cs < W;        // uniform (every wavefront stays for the barriers)
+  const int16_t* d = disp + (size_t)blockIdx.y * W * H;
+  SpkRun* const R = runs + (size_t)blockIdx.y * lay.records(H);   // this pair's records (dense block + plane)
+  int* const P = &R->parent;
+  unsigned* const sl = seam + (size_t)blockIdx.y * lay.seam_slots(nbands);   // this pair's seam lists
+  auto slot = [&](int r, int sg, int k) -> unsigned { return spk_slot((unsigned)((y0 + r) * S + sg), (unsigned)k, (unsigned)SW, (unsigned)(H * S), (unsigned)lay.D); };
+
+  // the pixels either side of the segment's left edge (lane = row): joined or not, decided after the walks
+  bool joined = false;
+  if (S > 1 && walks && seg > 0 && lane < G && y0 + lane < H) {
+    const int a = d[(size_t)(y0 + lane) * W + cs - 1], b = d[(size_t)(y0 + lane) * W + cs];
+    joined = a != newval && b != newval && abs(a - b) <= maxdiff;
+  }
+
+  int nh[G + 1], nsm = 0;
+#pragma unroll
+  for (int r = 0; r <= G; r++) nh[r] = 0;
+  bool over = false;
+  if (walks) over = speckle_band_walk<G, S, true>(d, R, sl, lay, W, H, newval, maxdiff, lds, wave, band, seg, cs, ce, nh, nsm);
+  if (S > 1 && lane == 0) lds.ovf[wave] = over ? 1 : 0;
+  sync(false);
+  bool global_mode = over;   // uniform per band
+  if constexpr (S > 1) {
+    for (int i = 0; i < S; i++) global_mode |= lds.ovf[bl * S + i] != 0;
+  }
+  if (global_mode && walks) speckle_band_walk<G, S, false>(d, R, sl, lay, W, H, newval, maxdiff, lds, wave, band, seg, cs, ce, nh, nsm);
+  if (S == 1 && band >= nbands) return;
+  if (band < nbands && lane == 0) {
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      if constexpr (S > 1) lds.nh[wave][r] = nh[r];
+      if (y0 + r < H) nheads[((size_t)blockIdx.y * H + y0 + r) * S + seg] = nh[r];
+    }
+    nseam[((size_t)blockIdx.y * nbands + band) * S + seg] = nsm;
+  }
+  sync(global_mode);
+
+  // ---- runs that cross the segment's left edge: this segment's first run of the row continues the left segment's last one
+  if (S > 1 && joined) {
+    const int kl = lds.nh[wave - 1][lane] - 1;
+    if (global_mode) uf_union<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, (int)slot(lane, seg - 1, kl), (int)slot(lane, seg, 0));
+    else lds_union(lds.par, (wave - 1) * N + lane * CAPR + kl, wave * N + lane * CAPR);
+  }
+  if (!global_mode) {
+#pragma unroll
+    for (int i = 0; i < N; i += 64) lds.cs[wave * N + i + lane] = 0u;   // (the contact lists are done with: sizes from here on)
+  }
+  sync(global_mode);
+
+  // ---- last phase: the band's components are final INSIDE the band. Every run learns the in-band size of its component, every
+  // in-band root is flagged: the seam / count / apply kernels then settle the bulk of the runs from the run's own record.
+  // Lanes = (row of the band, run of that row in this segment), 64 / G runs of every row at a time; two sweeps with the band's
+  // size sums between.
+  constexpr int LPR = 64 / G;                      // lanes per row
+  const int q = lane / LPR, li = lane - q * LPR;
+  int nhq = 0;
+#pragma unroll
+  for (int r = 0; r < G; r++) nhq = q == r ? nh[r] : nhq;
+  int nhmax = nh[0];
+#pragma unroll
+  for (int r = 1; r < G; r++) nhmax = max(nhmax, nh[r]);
+  int* const lsize = reinterpret_cast<int*>(lds.cs);
+  if (!global_mode) {
+    for (int base = 0; base < nhmax; base += LPR) {
+      const int k = base + li;
+      if (k < nhq) {
+        const int id = wave * N + q * CAPR + k;
+        const int root = lds_find(lds.par, id);
+        lds.par[id] = root;      // (a node's parent only ever moves towards its root: concurrent finds stay right)
+        __hip_atomic_fetch_add(&lsize[root], (int)lds.last[id] - (int)lds.first[id] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  } else {
+    for (int base = 0; base < nhmax; base += LPR) {
+      const int k = base + li;
+      if (k < nhq) {
+        const unsigned self = slot(q, seg, k);
+        SpkRun* const rec = at32(R, self);
+        const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int lst = __hip_atomic_load(&rec->last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int root = uf_find<__HIP_MEMORY_SCOPE_WORKGROUP, 4>(P, (int)self);
+        if (root != (int)self) __hip_atomic_store(&rec->parent, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // compressed: one step to the in-band root
+        __hip_atomic_fetch_add(&at32(R, (unsigned)root)->size, lst - fst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  if constexpr (S > 1) {
+    __syncthreads();   // the size sums are complete
+  } else if (global_mode) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!global_mode) {
+    for (int base = 0; base < nhmax; base += LPR) {
+      const int k = base + li;
+      if (k < nhq) {
+        const int id = wave * N + q * CAPR + k;
+        const int root = lds.par[id];
+        const int rw = root / N, rem = root - rw * N, rq = rem / CAPR, rk = rem - rq * CAPR;
+        // the record, complete, in one store: parent = the in-band root's slot, the component's in-band size, first (+ root flag), last
+        *reinterpret_cast<int4*>(at32(R, slot(q, seg, k))) = make_int4((int)slot(rq, rw - bl * S, rk), lsize[root],
+                                                                        (int)lds.first[id] | (root == id ? kSpkRootFlag : 0), (int)lds.last[id]);
+      }
+    }
+  } else {
+    for (int base = 0; base < nhmax; base += LPR) {
+      const int k = base + li;
+      if (k < nhq) {
+        const unsigned self = slot(q, seg, k);
+        SpkRun* const rec = at32(R, self);
+        const int root = __hip_atomic_load(&rec->parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (root == (int)self) {
+          const int fst = __hip_atomic_load(&rec->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          rec->first = fst | kSpkRootFlag;
+        } else {
+          rec->size = __hip_atomic_load(&at32(R, (unsigned)root)->size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
 }
 
 // Seam contacts of the band walk: one wavefront per band, 64 contacts at a time. Both records of a contact are loaded at once and
@@ -932,21 +1001,24 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
 // not matter (neither is a speckle, merged or not); one larger: the other one's in-band root is marked "touches something
 // large" (a plain store; the count kernel carries the mark to the final root if that root gets hooked); both small: union of the
 // two in-band roots.
+template <int S>
 __global__ void __launch_bounds__(256) speckle_seam_kernel(SpkRun* __restrict__ runs, const unsigned* __restrict__ seam,
-                                                            const int* __restrict__ nseam, int HS, int W, int H, int G, int maxsize) {
+                                                            const int* __restrict__ nseam, const SpkLayout<S> lay, int H, int G, int maxsize) {
   const int lane = threadIdx.x & 63;
   const int nbands = (H + G - 1) / G;
-  const int band = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (band >= nbands) return;
+  const int bandv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // virtual band: band * S + segment
+  if (bandv >= nbands * S) return;
+  const int band = bandv / S, seg = bandv - band * S;
   const int y = band * G + G - 1;   // upper row of the seam
   if (y + 1 >= H) return;
-  SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);
+  SpkRun* const R = runs + (size_t)blockIdx.y * lay.records(H);
   int* const P = &R->parent;
-  const unsigned* sl = seam + (size_t)blockIdx.y * ((size_t)nbands * kSpkDenseSeam + (size_t)nbands * HS);
-  const int n = nseam[(size_t)blockIdx.y * nbands + band];
+  const unsigned* sl = seam + (size_t)blockIdx.y * lay.seam_slots(nbands);
+  const int n = nseam[(size_t)blockIdx.y * nbands * S + bandv];
+  const unsigned yv = (unsigned)(y * S + seg), HV = (unsigned)(H * S);
   for (int i = lane; i < n; i += 64) {
-    const unsigned e = sl[spk_seam_slot(band, (unsigned)i, nbands, HS)];
-    const int a = (int)spk_slot(y, e & 0xffffu, W, H), b = (int)spk_slot(y + 1, e >> 16, W, H);
+    const unsigned e = sl[spk_seam_slot((unsigned)bandv, (unsigned)i, (unsigned)(nbands * S), (unsigned)lay.SW)];
+    const int a = (int)spk_slot(yv, e & 0xffffu, (unsigned)lay.SW, HV, (unsigned)lay.D), b = (int)spk_slot(yv + S, e >> 16, (unsigned)lay.SW, HV, (unsigned)lay.D);
     const int4 ra = *reinterpret_cast<const int4*>(R + a), rb = *reinterpret_cast<const int4*>(R + b);   // parent, size, first, last
     // (a record's size is its component's in-band size -- its own sum at a root; marks of this kernel only make it larger)
     const bool big_a = ra.y > maxsize, big_b = rb.y > maxsize;
@@ -1072,16 +1144,18 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(int16_t* __restrict_
 // ---- record-driven count / apply: one wavefront per image row, one lane per run ---------------------------------------------
 // count: only in-band roots that the seam kernel hooked under another root have anything to do -- their size (or their "touches
 // something large" mark) goes to the final root. Everything else leaves after one load.
+template <int S>
 __global__ void __launch_bounds__(256) speckle_count_list_kernel(SpkRun* __restrict__ runs, const int* __restrict__ nheads,
-                                                                  int W, int H, int maxsize) {
-  SPK_ROW_SETUP
-  if (y >= H) return;
-  (void)plane_off;
-  SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);
+                                                                  const SpkLayout<S> lay, int H, int maxsize) {
+  const int lane = threadIdx.x & 63;
+  const int HV = H * S;
+  const int yv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // virtual row: y * S + segment
+  if (yv >= HV) return;
+  SpkRun* const R = runs + (size_t)blockIdx.y * lay.records(H);
   int* const P = &R->parent;
-  const int nh = nheads[(size_t)blockIdx.y * H + y];
+  const int nh = nheads[(size_t)blockIdx.y * HV + yv];
   for (int i = lane; i < nh; i += 64) {
-    const int self = (int)spk_slot(y, i, W, H);
+    const int self = (int)spk_slot((unsigned)yv, (unsigned)i, (unsigned)lay.SW, (unsigned)HV, (unsigned)lay.D);
     const int4 rec = *reinterpret_cast<const int4*>(R + self);   // parent, size, first, last
     if (rec.z >= 0 || rec.x == self) continue;                   // not an in-band root / a root nobody hooked
     const int r = uf_root_final<4>(P, rec.x);
@@ -1097,16 +1171,19 @@ __global__ void __launch_bounds__(256) speckle_count_list_kernel(SpkRun* __restr
 
 // apply: a run whose component is large inside its own band stays (one load: the bulk); otherwise its in-band root decides, or --
 // if that root was hooked -- the final root.
+template <int S>
 __global__ void __launch_bounds__(256) speckle_apply_list_kernel(int16_t* __restrict__ disp, const SpkRun* __restrict__ runs,
-                                                                  const int* __restrict__ nheads, int W, int H, int newval,
-                                                                  int maxsize) {
-  SPK_ROW_SETUP
-  if (y >= H) return;
-  int16_t* d = disp + plane_off + (size_t)y * W;
-  const SpkRun* const R = runs + (size_t)blockIdx.y * ((size_t)H * kSpkDense + (size_t)W * H);
-  const int nh = nheads[(size_t)blockIdx.y * H + y];
+                                                                  const int* __restrict__ nheads, const SpkLayout<S> lay, int W, int H,
+                                                                  int newval, int maxsize) {
+  const int lane = threadIdx.x & 63;
+  const int HV = H * S;
+  const int yv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // virtual row: y * S + segment
+  if (yv >= HV) return;
+  int16_t* d = disp + (size_t)blockIdx.y * W * H + (size_t)(yv / S) * W;
+  const SpkRun* const R = runs + (size_t)blockIdx.y * lay.records(H);
+  const int nh = nheads[(size_t)blockIdx.y * HV + yv];
   for (int i = lane; i < nh; i += 64) {
-    const int self = (int)spk_slot(y, i, W, H);
+    const int self = (int)spk_slot((unsigned)yv, (unsigned)i, (unsigned)lay.SW, (unsigned)HV, (unsigned)lay.D);
     const int4 rec = *reinterpret_cast<const int4*>(R + self);
     if (rec.y > maxsize) continue;
     int4 root = rec;
@@ -1130,7 +1207,6 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
   dim3 grid((g.H + 3) / 4, g.n);
   if (g.reading & kReadSpeckleX16) max_diff = (int)std::min<long>((long)max_diff * 16, 1L << 17);
   max_diff = std::min(max_diff, 1 << 17);   // int16 values: any larger range joins everything alike
-  const int HS = g.W;   // seam-list slots per band: at most one contact per pixel of the seam
   // Two implementations. Default: band walk (runs + merge in one pass, G rows per wavefront) + seam unions,
   // then count and apply driven by the rows' run records (16-bit run indices: W <= 65535; 32-bit byte offsets within an image's
   // record plane). Fallback (SBM_SPECKLE_LISTS=0 or SBM_SPECKLE_BAND=0, or outside those limits): four kernels that each walk
@@ -1139,8 +1215,8 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
   const int lists_env = env_switch("SBM_SPECKLE_LISTS", 1);
   const int band_env = env_switch("SBM_SPECKLE_BAND", -1);
   // (maxSpeckleSize beyond kSpkMaxSize: the row-walking kernels -- see the count kernel's size sums)
-  const bool lists = nheads && seam && nseam && g.W <= 65535 && (long)g.W * g.H < (1L << 27) && max_size <= kSpkMaxSize && lists_env != 0 &&
-                     band_env != 0;
+  const bool lists = nheads && seam && nseam && g.W <= 65535 && ((long)g.W + kSpkRecordPad) * g.H < (1L << 27) && max_size <= kSpkMaxSize &&
+                     lists_env != 0 && band_env != 0;
   if (lists) {
     SpkRun* R = static_cast<SpkRun*>(runs);
     // 4 rows per wavefront once that still leaves ~6 000 band wavefronts (6 per SIMD), else 2: the walk of a band is a serial
@@ -1148,16 +1224,28 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
     int G = (long)g.n * g.H >= 24000 ? 4 : 2;
     if (band_env == 2 || band_env == 4) G = band_env;
     const int nbands = (g.H + G - 1) / G;
-    dim3 bgrid((nbands + 3) / 4, g.n);
-    if (G == 4)
-      hipLaunchKernelGGL(speckle_band_kernel<4>, bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, HS, g.W, g.H, g.filtered,
-                         max_diff);
-    else
-      hipLaunchKernelGGL(speckle_band_kernel<2>, bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, HS, g.W, g.H, g.filtered,
-                         max_diff);
-    hipLaunchKernelGGL(speckle_seam_kernel, bgrid, dim3(256), 0, s, R, seam, nseam, HS, g.W, g.H, G, max_size);
-    hipLaunchKernelGGL(speckle_count_list_kernel, grid, dim3(256), 0, s, R, nheads, g.W, g.H, max_size);
-    hipLaunchKernelGGL(speckle_apply_list_kernel, grid, dim3(256), 0, s, disp, R, nheads, g.W, g.H, g.filtered, max_size);
+    // Column segments per band (wavefronts of one workgroup): the walk of a band is a serial chain, so launches that leave the
+    // chip room are cut finer. SBM_SPECKLE_SEG=1/2/4 forces a count.
+    const int nchunks = (g.W + 63) / 64;
+    const long pairs_of_rows = (long)g.n * ((g.H + 1) / 2);
+    int S = pairs_of_rows < kSpkSeg4 ? 4 : (pairs_of_rows < kSpkSeg2 ? 2 : 1);
+    const int seg_env = env_switch("SBM_SPECKLE_SEG", 0);
+    if (seg_env == 1 || seg_env == 2 || seg_env == 4) S = seg_env;
+    while (S > 1 && nchunks < S) S >>= 1;
+    dim3 bgrid((nbands * S + 3) / 4, g.n), vgrid((g.H * S + 3) / 4, g.n);
+    const int SW = 64 * ((nchunks + S - 1) / S), newval = g.filtered;
+    auto launch = [&](auto seg) {
+      constexpr int SS = decltype(seg)::value;
+      const SpkLayout<SS> lay{SW};
+      if (G == 4) hipLaunchKernelGGL((speckle_band_kernel<4, SS>), bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
+      else hipLaunchKernelGGL((speckle_band_kernel<2, SS>), bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
+      hipLaunchKernelGGL(speckle_seam_kernel<SS>, bgrid, dim3(256), 0, s, R, seam, nseam, lay, g.H, G, max_size);
+      hipLaunchKernelGGL(speckle_count_list_kernel<SS>, vgrid, dim3(256), 0, s, R, nheads, lay, g.H, max_size);
+      hipLaunchKernelGGL(speckle_apply_list_kernel<SS>, vgrid, dim3(256), 0, s, disp, R, nheads, lay, g.W, g.H, newval, max_size);
+    };
+    if (S == 4) launch(std::integral_constant<int, 4>{});
+    else if (S == 2) launch(std::integral_constant<int, 2>{});
+    else launch(std::integral_constant<int, 1>{});
   } else {
     int* labels = static_cast<int*>(runs);
     int* counts = labels + (size_t)g.n * g.W * g.H;
