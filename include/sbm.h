@@ -31,8 +31,8 @@
  * would see a wrapped cost where this engine (and its oracle) keep the true one.
  *
  * Limits (SBM_ERR_UNSUPPORTED beyond them; cv::StereoBM itself has none of these): numDisparities <= 4096, at most 32 767 pairs
- * per call, image height <= 65 535. The speckle filter's band walk serves images up to 2^27 pixels and 65 535 columns, larger
- * ones its row-walking kernels (same results).
+ * per call, image height <= 65 535. The speckle filter's band walk serves images up to 2^27 pixels and 65 535 columns and
+ * speckleWindowSize up to 2048; larger images or windows take its row-walking kernels (same results, ~3x the stage time).
  *
  * The hand-tuned kernels accumulate in place with v_mqsad_pk_u16_u8 (vdst == src2), which the hardware does right and the
  * compiler's register model forbids; a device self-test (once per device and process, on the first handle's stream: pseudo-random
@@ -42,7 +42,7 @@
  * and up to 256 disparities -- block sizes 29 / 31 and 257..512 disparities then fall to the sliding-sum kernel (8-25x slower; the
  * kernel name, sbm_last_kernel_name(), then reads "sad_wide_kernel [in-place accumulate unavailable]").
  *
- * Environment. The library reads these eight variables (nothing else); an integrator never needs to set any of them:
+ * Environment. The library reads these nine variables (nothing else); an integrator never needs to set any of them:
  *   variable            default  read      who sets it, and what for
  *   SBM_FAST_INPLACE    1        once      0 = run the two-accumulator build of the SAD kernel (the fallback that is taken
  *                                          automatically when the device self-test of the in-place v_mqsad accumulate
@@ -54,6 +54,8 @@
  *                                          instead of the band walk + run records; GPU tests
  *   SBM_SPECKLE_BAND    auto     per call  2 / 4 = band height of the speckle filter's band walk, 0 = row-walking kernels;
  *                                          GPU tests
+ *   SBM_SPECKLE_SEG     auto     per call  1 / 2 / 4 = column segments per band of the band walk (wavefronts of one workgroup that
+ *                                          walk a band together; automatic: 4 for one-pair calls, 1 for frame batches); GPU tests
  *   SBM_HOST_ZEROCOPY   1        per call  0 = small host-buffer calls (sbm_compute / sbm_compute_batch up to 8 MB of maps) into
  *                                          pageable memory return their maps through a D2H copy + stream synchronisation instead of
  *                                          the copy kernel that writes pinned host memory and raises a flag the host polls; GPU

@@ -12,7 +12,7 @@ namespace sbm {
 // Environment switches of the library -- the complete list, documented for integrators in include/sbm.h ("Environment").
 //   env_switch(): read in every build. They select a tested fallback or a code path that the GPU tests compare with the
 //                 default one: SBM_FAST_INPLACE, SBM_FAST_PFSHIFT, SBM_FAST_CS3, SBM_SPECKLE_LISTS, SBM_SPECKLE_BAND,
-//                 SBM_HOST_ZEROCOPY, SBM_WIDE, SBM_CV_READING.
+//                 SBM_SPECKLE_SEG, SBM_HOST_ZEROCOPY, SBM_WIDE, SBM_CV_READING.
 //   SBM_TUNE():   tuning knobs behind the sweeps of tools/exp (SBM_FAST_NSEG, SBM_FAST_TAPER,
 //                 SBM_FAST_UNIQ_PLAIN, SBM_FAST_SPLIT, SBM_PF_ROWS, SBM_HOST_CHUNK, SBM_HOST_PIPELINE, SBM_DEV_*): compiled in
 //                 only with -DSBM_DEV (the development library of tools/exp/r05_devlib.sh; sbm_sad_fast_dev.h lists the interior

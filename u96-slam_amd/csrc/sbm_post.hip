@@ -579,16 +579,21 @@ constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x100
 #endif
 template <int G>
 constexpr int kSpkCapR = G == 2 ? SPK_CAPR2 : SPK_CAPR4;
-template <int G>
+#ifndef SPK_NW1
+#define SPK_NW1 4
+#endif
+template <int S>
+constexpr int kSpkWaves = S == 1 ? SPK_NW1 : 4;   // wavefronts per workgroup of the band walk
+template <int G, int NW = 4>
 struct SpkWgLds {
   static constexpr int N = G * kSpkCapR<G>;   // run ids of one wavefront
-  int par[4 * N];
-  unsigned short first[4 * N], last[4 * N];   // (the band walk serves up to 65 535 columns)
+  int par[NW * N];
+  unsigned short first[NW * N], last[NW * N];   // (the band walk serves up to 65 535 columns)
   // walk: the wavefront's own N entries are its contact list (LOCAL: upper id | lower id << 16; GLOBAL: N / 2 pairs of record
   // slots); last phase: in-band size of a component, at its root
-  unsigned cs[4 * N];
-  int nh[4][G];    // runs per owned row of every wavefront (the segment to the right joins its first run to this one's last)
-  int ovf[4];      // LOCAL mode ran out of run ids
+  unsigned cs[NW * N];
+  int nh[NW][G];   // runs per owned row of every wavefront (the segment to the right joins its first run to this one's last)
+  int ovf[NW];     // LOCAL mode ran out of run ids
 };
 static_assert(SpkWgLds<2>::N / 2 > 64 && SpkWgLds<4>::N / 2 > 64 * 3 && 4 * SpkWgLds<2>::N <= 65536 && 4 * SpkWgLds<4>::N <= 65536, "");
 
@@ -624,7 +629,7 @@ struct SpkLayout {
 // then: the band is walked again in GLOBAL mode). nh[r]: runs of row r in this segment; nsm: seam contacts listed.
 template <int G, int S, bool LOCAL>
 __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d, SpkRun* __restrict__ R, unsigned* __restrict__ sl,
-                                                  const SpkLayout<S> lay, int W, int H, int newval, int maxdiff, SpkWgLds<G>& lds,
+                                                  const SpkLayout<S> lay, int W, int H, int newval, int maxdiff, SpkWgLds<G, kSpkWaves<S>>& lds,
                                                   const int wave, const int band, const int seg, const int cs, const int ce,
                                                   int (&nh)[G + 1], int& nsm) {
   constexpr int CAPR = kSpkCapR<G>;
@@ -843,15 +848,16 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d,
   return false;
 }
 
-// grid: (ceil(nbands * S / 4), n), block 256 = 4 wavefronts = 4 / S bands x S column segments
+// grid: (ceil(nbands * S / NW), n), block = NW wavefronts = NW / S bands x S column segments
 template <int G, int S>
-__global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
+__global__ void __launch_bounds__(64 * kSpkWaves<S>) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
                                                             int* __restrict__ nheads, unsigned* __restrict__ seam,
                                                             int* __restrict__ nseam, const SpkLayout<S> lay, int W, int H, int newval,
                                                             int maxdiff) {
   constexpr int CAPR = kSpkCapR<G>;
   constexpr int N = SpkWgLds<G>::N;
-  __shared__ SpkWgLds<G> lds;
+  constexpr int NW = kSpkWaves<S>;
+  __shared__ SpkWgLds<G, NW> lds;
   const int lane = threadIdx.x & 63;
   const int SW = lay.SW;
   // S = 1: the four wavefronts are four bands that have nothing to do with each other -- no workgroup barriers
@@ -867,7 +873,7 @@ __global__ void __launch_bounds__(256) speckle_band_kernel(const int16_t* __rest
   const int nbands = (H + G - 1) / G;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: keeps row pointers and counters in SGPRs
   const int bl = wave / S, seg = wave - bl * S;
-  const int band = blockIdx.x * (4 / S) + bl;
+  const int band = blockIdx.x * (NW / S) + bl;
   const int y0 = band * G;
   const int cs = seg * SW, ce = min(W, cs + SW);
   const bool walks = band < nbands && cs < W;        // uniform (every wavefront stays for the barriers)
@@ -1237,8 +1243,9 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
     auto launch = [&](auto seg) {
       constexpr int SS = decltype(seg)::value;
       const SpkLayout<SS> lay{SW};
-      if (G == 4) hipLaunchKernelGGL((speckle_band_kernel<4, SS>), bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
-      else hipLaunchKernelGGL((speckle_band_kernel<2, SS>), bgrid, dim3(256), 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
+      const dim3 wgrid((nbands * SS + kSpkWaves<SS> - 1) / kSpkWaves<SS>, g.n), wblock(64 * kSpkWaves<SS>);
+      if (G == 4) hipLaunchKernelGGL((speckle_band_kernel<4, SS>), wgrid, wblock, 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
+      else hipLaunchKernelGGL((speckle_band_kernel<2, SS>), wgrid, wblock, 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
       hipLaunchKernelGGL(speckle_seam_kernel<SS>, bgrid, dim3(256), 0, s, R, seam, nseam, lay, g.H, G, max_size);
       hipLaunchKernelGGL(speckle_count_list_kernel<SS>, vgrid, dim3(256), 0, s, R, nheads, lay, g.H, max_size);
       hipLaunchKernelGGL(speckle_apply_list_kernel<SS>, vgrid, dim3(256), 0, s, disp, R, nheads, lay, g.W, g.H, newval, max_size);
