@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Soak test on the GPU: many seeded random configurations (sizes, windows 5..29, disparity counts, every post-filter
 combination, batches; since round 5 windows up to 41 and up to 528 disparities: the 3 / 4-wavefront layouts and the sliding-sum
-fallback kernel) against the oracle, stage by stage; every configuration is also run twice for determinism.
+fallback kernel; since round 6 a random band height and segment count of the speckle filter's band walk and speckle windows
+beyond its 2048-pixel limit) against the oracle, stage by stage; every configuration is also run twice for determinism.
 usage: python tools/soak.py [--iters 400] [--seed 1]   -> prints a JSON summary, exit code 1 on any mismatch"""
 import argparse
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -62,7 +64,13 @@ def main():
         if rng.random() < 0.15:
             kw.update(prefilter_type=0, prefilter_size=int(rng.choice([5, 9, 9, 15, 31, 63])))
         if rng.random() < 0.6:
-            kw.update(speckle_window_size=int(rng.choice([1, 10, 50, 200, 1000])), speckle_range=int(rng.choice([0, 4, 16, 32, 100])))
+            kw.update(speckle_window_size=int(rng.choice([1, 10, 50, 200, 1000, 2048, 3000])), speckle_range=int(rng.choice([0, 4, 16, 32, 100])))
+        # round 6: the speckle filter's band walk in every shape (band height x column segments per band; unset = automatic)
+        for var, choices in (("SBM_SPECKLE_BAND", ["", "", "2", "4"]), ("SBM_SPECKLE_SEG", ["", "", "1", "2", "4"])):
+            v = str(rng.choice(choices))
+            os.environ.pop(var, None)
+            if v:
+                os.environ[var] = v
         pairs = [rand_pair(rng, h, w, shift=int(rng.integers(0, 14)), noise=int(rng.integers(0, 8))) for _ in range(n)]
         L = np.stack([p[0] for p in pairs]); R = np.stack([p[1] for p in pairs])
         if rng.random() < 0.3:
