@@ -31,7 +31,7 @@
  * would see a wrapped cost where this engine (and its oracle) keep the true one.
  *
  * Limits (SBM_ERR_UNSUPPORTED beyond them; cv::StereoBM itself has none of these): numDisparities <= 4096, at most 32 767 pairs
- * per call, image height <= 65 535. The speckle filter's band walk serves images up to 2^27 pixels and 65 535 columns and
+ * per call, image height <= 65 535. The speckle filter's band walk serves images up to 65 535 columns and (W + 288) * H < 2^27 and
  * speckleWindowSize up to 2048; larger images or windows take its row-walking kernels (same results, ~3x the stage time).
  *
  * The hand-tuned kernels accumulate in place with v_mqsad_pk_u16_u8 (vdst == src2), which the hardware does right and the

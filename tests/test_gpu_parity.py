@@ -722,6 +722,26 @@ def test_speckle_band_walk_variants(pkg, oracle, band, seg, shape, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spw", [2047, 2048, 2049, 6000])
+@pytest.mark.parametrize("wsz", [9, 21])
+def test_speckle_windows_around_the_band_walk_limit(pkg, oracle, golden, spw, wsz):
+    """maxSpeckleSize up to 2048 runs the band walk (its size marks need that bound, include/sbm.h), beyond it the row-walking
+    kernels: components of thousands of pixels erased or kept exactly like the oracle on the reference's pair, five calls each
+    (the size sums of a component that spans many bands are racing atomic adds)."""
+    kw = dict(num_disparities=64, block_size=wsz, prefilter_cap=31, texture_threshold=10, uniqueness_ratio=10,
+              speckle_window_size=spw, speckle_range=32, disp12_max_diff=1)
+    p = oracle.make_params(**kw)
+    ref = oracle.compute(p, golden["rect_l"], golden["rect_r"])
+    pre = oracle.compute(oracle.make_params(**dict(kw, speckle_window_size=0)), golden["rect_l"], golden["rect_r"])
+    assert int(((pre >= 0) & (ref < 0)).sum()) > spw      # the filter erased more than one window's worth: large components took part
+    bm = pkg.StereoBM.create(64, wsz)
+    bm.setTextureThreshold(10); bm.setUniquenessRatio(10); bm.setSpeckleWindowSize(spw); bm.setSpeckleRange(32); bm.setDisp12MaxDiff(1)
+    for rep in range(5):
+        got = bm.compute(golden["rect_l"], golden["rect_r"])
+        assert np.array_equal(got, ref), (rep, int((got != ref).sum()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seg", ["1", "4"])
 @pytest.mark.parametrize("lists,band", [("1", "-1"), ("1", "0"), ("1", "2"), ("1", "4"), ("0", "-1")])
 def test_speckle_with_one_run_per_pixel(pkg, oracle, lists, band, seg, monkeypatch):
