@@ -749,48 +749,40 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d,
         // ---- general path. Run heads of every row; the vertical contacts first (a lane's run is the row's count of runs
         // before this chunk + the heads at or below the lane), then the records of the owned rows.
         unsigned long long head[G + 1];
+        int nhd[G + 1], run[G + 1];   // heads of the row in this chunk (uniform); index of the lane's run within its row (valid lanes only)
 #pragma unroll
-        for (int r = 0; r <= G; r++) head[r] = vm[r] & __ballot(th[r] > tm);
-        auto run_of = [&](int r) -> int {   // index of the lane's run within its row; valid lanes only
-          return nh[r] - 1 + lanes_below(head[r]) + (int)((head[r] >> lane) & 1ull);
-        };
+        for (int r = 0; r <= G; r++) {
+          head[r] = vm[r] & __ballot(th[r] > tm);
+          nhd[r] = __popcll(head[r]);
+          run[r] = nh[r] - 1 + lanes_below(head[r]) + (lane_in(head[r]) ? 1 : 0);
+        }
         if constexpr (LOCAL) {
           // out of slots? (uniform) -> the band is walked again in GLOBAL mode
           bool full = false;
 #pragma unroll
-          for (int r = 0; r < G; r++) full |= nh[r] + __popcll(head[r]) > CAPR;
+          for (int r = 0; r < G; r++) full |= nh[r] + nhd[r] > CAPR;
           if (full) return true;
-          // the heads of this chunk open their records (the contacts that name them are unioned later, in batches)
-#pragma unroll
-          for (int r = 0; r < G; r++) {
-            const unsigned long long hm = head[r];
-            if (hm && lane_in(hm)) {
-              const int id = idbase + r * CAPR + nh[r] + lanes_below(hm);
-              lds.par[id] = id;
-              lds.first[id] = (unsigned short)(cb + lane);
-            }
-          }
         }
+        // (the blocks below are predicated, not branched around: an empty mask skips the body by itself, and the uniform counts
+        // are two scalar instructions -- cheaper than the compare-and-branch that would avoid them)
 #pragma unroll
         for (int r = 1; r <= G; r++) {
           const unsigned long long cdm = __ballot(tv[r] <= tm);
           const unsigned long long pcdm = __ballot((unsigned)(pv[r] + maxdiff - pv[r - 1]) <= tm);   // the same, one pixel left
           // first pixel of a contact between two runs: not the same two runs as at the pixel to the left
           const unsigned long long fm = cdm & (head[r - 1] | head[r] | ~pcdm);
-          if (fm) {
-            if (lane_in(fm)) {
-              const int k = lanes_below(fm);
-              const int ku = run_of(r - 1), kd = run_of(r);
-              if (r < G) {
-                if constexpr (LOCAL) clist[count + k] = (unsigned)(idbase + (r - 1) * CAPR + ku) | ((unsigned)(idbase + r * CAPR + kd) << 16);
-                else list[count + k] = make_int2((int)slot(r - 1, ku), (int)slot(r, kd));
-              } else {
-                *at32(sl, spk_seam_slot(bandv, (unsigned)(nsm + k), nbandsv, SW)) = (unsigned)ku | ((unsigned)kd << 16);
-              }
+          if (lane_in(fm)) {
+            const int k = lanes_below(fm);
+            const int ku = run[r - 1], kd = run[r];
+            if (r < G) {
+              if constexpr (LOCAL) clist[count + k] = (unsigned)(idbase + (r - 1) * CAPR + ku) | ((unsigned)(idbase + r * CAPR + kd) << 16);
+              else list[count + k] = make_int2((int)slot(r - 1, ku), (int)slot(r, kd));
+            } else {
+              *at32(sl, spk_seam_slot(bandv, (unsigned)(nsm + k), nbandsv, SW)) = (unsigned)ku | ((unsigned)kd << 16);
             }
-            if (r < G) count += __popcll(fm);
-            else nsm += __popcll(fm);
           }
+          if (r < G) count += __popcll(fm);
+          else nsm += __popcll(fm);
         }
         // run records of the owned rows, in column order: a head opens the row's next record, a boundary pixel (a head or an
         // invalid pixel) right of a valid one closes the oldest open one -- the k-th start and the k-th end are the same run.
@@ -798,29 +790,29 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d,
         for (int r = 0; r < G; r++) {
           const unsigned long long hm = head[r];
           const unsigned long long em = __ballot(pv[r] < kSpkFarMin) & (hm | ~vm[r]);
-          if constexpr (!LOCAL) {
-            if (hm) {
-              if (lane_in(hm)) {
-                const unsigned self = slot(r, nh[r] + lanes_below(hm));
-                int* q = &at32(R, self)->parent;
-                // parent = self, size = 0 (summed in the last phase), first column; the last column follows when the run ends
-                __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                q[1] = 0;
-                q[2] = cb + lane;
-              }
+          if (lane_in(hm)) {   // (a head's run index is the row's count before the chunk + the heads left of it)
+            if constexpr (LOCAL) {
+              const int id = idbase + r * CAPR + run[r];
+              lds.par[id] = id;
+              lds.first[id] = (unsigned short)(cb + lane);
+            } else {
+              const unsigned self = slot(r, run[r]);
+              int* q = &at32(R, self)->parent;
+              // parent = self, size = 0 (summed in the last phase), first column; the last column follows when the run ends
+              __hip_atomic_store(q, (int)self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              q[1] = 0;
+              q[2] = cb + lane;
             }
           }
-          if (em) {
-            if (lane_in(em)) {
-              const int k = ne[r] + lanes_below(em);
-              if constexpr (LOCAL) lds.last[idbase + r * CAPR + k] = (unsigned short)(cb + lane - 1);
-              else at32(R, slot(r, k))->last = cb + lane - 1;
-            }
-            ne[r] += __popcll(em);
+          if (lane_in(em)) {
+            const int k = ne[r] + lanes_below(em);
+            if constexpr (LOCAL) lds.last[idbase + r * CAPR + k] = (unsigned short)(cb + lane - 1);
+            else at32(R, slot(r, k))->last = cb + lane - 1;
           }
+          ne[r] += __popcll(em);
         }
 #pragma unroll
-        for (int r = 0; r <= G; r++) nh[r] += __popcll(head[r]);
+        for (int r = 0; r <= G; r++) nh[r] += nhd[r];
         if (count > (LOCAL ? N : N / 2) - 64 * (G - 1)) flush();   // a chunk adds at most 64 contacts per row pair
       }
       prev_empty = !quiet && empty;
