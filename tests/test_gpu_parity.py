@@ -722,6 +722,28 @@ def test_speckle_band_walk_variants(pkg, oracle, band, seg, shape, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("band,seg", [("2", "2"), ("2", "4"), ("4", "2"), ("4", "4"), ("4", "1")])
+def test_speckle_band_walk_overflows_its_lds_table_with_segments(pkg, oracle, band, seg, monkeypatch):
+    """More runs in a row of a column segment than the band walk's LDS table holds (128 at 4 rows per band, 256 at 2): the
+    band is walked again with its records in memory, by every wavefront of the band, and the runs that cross a segment edge are
+    joined by L2 atomics instead of LDS ones. speckleRange 0 on noise 1 100 columns wide: segments of 320 / 576 columns with a
+    run per pixel nearly everywhere, next to rows that are cleared to one long invalid stretch (bands that do NOT overflow in
+    the same workgroups)."""
+    monkeypatch.setenv("SBM_SPECKLE_BAND", band)
+    monkeypatch.setenv("SBM_SPECKLE_SEG", seg)
+    rng = np.random.default_rng(7)
+    L = rng.integers(0, 256, (2, 70, 1100), dtype=np.uint8)
+    R = rng.integers(0, 256, (2, 70, 1100), dtype=np.uint8)
+    L[:, 20:32] = 128; R[:, 20:32] = 128          # textureless rows: everything filtered, bands without a single run
+    kw = dict(num_disparities=64, block_size=5, texture_threshold=5, uniqueness_ratio=0, speckle_window_size=4, speckle_range=0,
+              disp12_max_diff=-1)
+    eng, ref = run_engine(pkg, oracle, kw, L, R)
+    assert_stages_equal(eng, ref, kw)
+    runs = (eng["pre_lr"][0] >= 0).sum(axis=1)
+    assert runs.max() > 4 * 256 * 0.5 and runs.min() == 0     # rows far beyond every table size, and rows without runs
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("spw", [2047, 2048, 2049, 6000])
 @pytest.mark.parametrize("wsz", [9, 21])
 def test_speckle_windows_around_the_band_walk_limit(pkg, oracle, golden, spw, wsz):
