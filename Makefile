@@ -5,7 +5,7 @@ CSRC := $(PKG)/csrc
 LIB := $(PKG)/lib/libsbm_hip.so
 # --offload-compress: the device code objects are stored compressed (10.5 MB -> 2.3 MB; ~4 ms of decompression at first use)
 HIPFLAGS ?= --offload-arch=gfx950 --offload-compress -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
-SRCS := $(CSRC)/sbm_api.hip $(CSRC)/sbm_prefilter.hip $(CSRC)/sbm_sad_generic.hip $(CSRC)/sbm_sad_wide.hip $(CSRC)/sbm_sad_fast.hip $(CSRC)/sbm_sad_fast_pw1.hip $(CSRC)/sbm_sad_fast_pw2.hip $(CSRC)/sbm_sad_fast_pw3.hip $(CSRC)/sbm_sad_fast_pp.hip $(CSRC)/sbm_post.hip $(CSRC)/sbm_consume.hip $(CSRC)/sbm_rectify.hip $(CSRC)/sbm_fpga.hip $(CSRC)/sbm_gftt.hip
+SRCS := $(CSRC)/sbm_api.hip $(CSRC)/sbm_prefilter.hip $(CSRC)/sbm_sad_generic.hip $(CSRC)/sbm_sad_wide.hip $(CSRC)/sbm_sad_fast.hip $(CSRC)/sbm_sad_fast_pw1.hip $(CSRC)/sbm_sad_fast_pw2.hip $(CSRC)/sbm_sad_fast_pw3.hip $(CSRC)/sbm_sad_fast_pp.hip $(CSRC)/sbm_lrcheck.hip $(CSRC)/sbm_speckle.hip $(CSRC)/sbm_consume.hip $(CSRC)/sbm_rectify.hip $(CSRC)/sbm_fpga.hip $(CSRC)/sbm_gftt.hip
 OBJS := $(SRCS:.hip=.o)
 
 all: $(LIB) oracle

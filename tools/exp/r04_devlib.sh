@@ -6,4 +6,4 @@ cd "$(dirname "$0")/../.."
 C=u96-slam_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSBM_DEV -DSBM_DEV_FEW $EXTRA -c $C/sbm_sad_fast.hip -o /tmp/sad_fast_dev.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o u96-slam_amd/lib/${OUT:-libsbm_hip_dev.so} $C/sbm_api.o $C/sbm_prefilter.o $C/sbm_sad_generic.o /tmp/sad_fast_dev.o \
-  $C/sbm_sad_fast_pp.o $C/sbm_post.o $C/sbm_consume.o $C/sbm_rectify.o $C/sbm_fpga.o $C/sbm_gftt.o
+  $C/sbm_sad_fast_pp.o $C/sbm_lrcheck.o $C/sbm_speckle.o $C/sbm_consume.o $C/sbm_rectify.o $C/sbm_fpga.o $C/sbm_gftt.o

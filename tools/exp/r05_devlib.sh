@@ -9,4 +9,4 @@ O=/tmp/sad_fast_${OUT%.so}.o
 FEW=-DSBM_DEV_FEW; [ "${FULL:-0}" = 1 ] && FEW=; [ -n "$FEWSET" ] && FEW=$FEWSET
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSBM_DEV $FEW $EXTRA -c $C/sbm_sad_fast.hip -o $O
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o u96-slam_amd/lib/$OUT $C/sbm_api.o $C/sbm_prefilter.o $C/sbm_sad_generic.o $C/sbm_sad_wide.o $O \
-  $C/sbm_sad_fast_pw1.o $C/sbm_sad_fast_pw2.o $C/sbm_sad_fast_pw3.o $C/sbm_sad_fast_pp.o $C/sbm_post.o $C/sbm_consume.o $C/sbm_rectify.o $C/sbm_fpga.o $C/sbm_gftt.o
+  $C/sbm_sad_fast_pw1.o $C/sbm_sad_fast_pw2.o $C/sbm_sad_fast_pw3.o $C/sbm_sad_fast_pp.o $C/sbm_lrcheck.o $C/sbm_speckle.o $C/sbm_consume.o $C/sbm_rectify.o $C/sbm_fpga.o $C/sbm_gftt.o

@@ -284,7 +284,7 @@ __device__ __forceinline__ void sad_border_wave_body(const FastArgs& a, unsigned
   auto flush = [&] {
     if (fvalid) {
       *fdisp = (int16_t)out_prev;
-      if (fcost) *fcost = (uint16_t)cost_prev;   // (0xffff for a filtered pixel: the LR kernel relies on it, sbm_post.hip)
+      if (fcost) *fcost = (uint16_t)cost_prev;   // (0xffff for a filtered pixel: the LR kernel relies on it, sbm_lrcheck.hip)
     }
     fdisp += a.W;
     if (fcost) fcost += a.W;

@@ -263,7 +263,7 @@ __device__ __forceinline__ void sad_fast_pp_strip(const FastArgs& a, const int c
       // ---- uniqueness (part 2): any d outside [mind-1, mind+1] with S[d] <= thresh rejects ---------------------
       if (a.uniq > 0) ok = ok && fast_unique(acc_lo, acc_hi, T, minsad, mind, nn, pp, a.nd);
       if (produces) {
-        int out = a.filtered, cst = 0xffff;   // (a filtered pixel's cost reads 0xffff: the LR kernel relies on it, sbm_post.hip)
+        int out = a.filtered, cst = 0xffff;   // (a filtered pixel's cost reads 0xffff: the LR kernel relies on it, sbm_lrcheck.hip)
         if (ok) {
           out = fast_subpixel(nn, pp, minsad, mind, a.nd, a.mindisp);
           cst = minsad >> a.pfshift;
