@@ -234,32 +234,30 @@ __global__ void __launch_bounds__(256) speckle_merge_kernel(const int16_t* __res
 }
 
 // ---- band walk: runs + merge in one pass ---------------------------------------------------------------------------------
-// One wavefront owns G consecutive rows (a band) and walks them together, chunk by chunk (64 columns), with the band's next
-// row as a look-ahead. Contacts between two rows of the band are unioned by the band's own wavefront (nobody else touches the
-// band's runs in this kernel); contacts across the seam to the next band go to a per-band list (upper run | lower run << 16)
-// and are unioned by speckle_seam_kernel once every band is done.
+// G consecutive rows (a band) are walked together, chunk by chunk (64 columns), with the band's next row as a look-ahead -- by
+// one wavefront, or by the S wavefronts of a workgroup with one column segment each (further down). Contacts between two rows
+// of the band are unioned inside the kernel (nobody else touches the band's runs in it); contacts across the seam to the next
+// band go to a list per band and segment (upper run | lower run << 16) and are unioned by speckle_seam_kernel once every band
+// is done.
 //
-// Round 6, data: a RUN is the unit of everything downstream, so runs get compact 16-byte records -- run k of row y lives in
-// slot spk_slot(y, k) of the pair's record area: parent (union-find), size (accumulated at the root by
-// the count kernel), first and last column. A row of a disparity map holds a handful of runs, so its records share one or two
-// cache lines; the round-5 layout (labels and sizes indexed by the PIXEL of the run head, lists elsewhere) cost a cache line
-// of HBM traffic per run and array -- the unions, the count and the apply kernel were chains of DRAM round trips. The k-th
-// run of a row is the same run for the wavefront that owns the row and for the one that looks ahead into it, so contacts
-// name runs by their index and the walk carries a run COUNT per row instead of the column of the last head.
-// Round 6, walk: built around what a disparity map looks like -- long runs. Per chunk, plain per-lane arithmetic decides
-// whether ANYTHING happens in it: every pixel of every row valid and joined to its left neighbour, every vertical pair in
-// contact (also at the pixel left of the chunk)  =>  no run starts, no run ends, no new contact, no state changes: the chunk
-// costs ~45 vector instructions and the scalar unit nothing (86 % of the chunks of the bench frames; the general path --
-// wavefront-uniform mask algebra, list appends -- runs on the rest). Chunks without a single valid pixel behind such a chunk
-// are skipped likewise.
+// Data: a RUN is the unit of everything downstream, so runs get compact 16-byte records -- run k of row y (and segment) lives in
+// slot spk_slot(...) of the pair's record area: parent (union-find), size, first and last column. A row of a disparity map holds
+// a handful of runs, so its records share one or two cache lines (labels and sizes indexed by the PIXEL of the run head, as the
+// row-walking kernels above keep them, cost a cache line of HBM traffic per run and array). The k-th run of a row is the same
+// run for the wavefront that owns the row and for the one that looks ahead into it, so contacts name runs by their index and
+// the walk carries a run COUNT per row.
+// Walk: built around what a disparity map looks like -- long runs. Per chunk, plain per-lane arithmetic decides whether ANYTHING
+// happens in it: every pixel of every row valid and joined to its left neighbour, every vertical pair in contact (also at the
+// pixel left of the chunk)  =>  no run starts, no run ends, no new contact, no state changes: the chunk costs ~45 vector
+// instructions and the scalar unit nothing (86 % of the (row, chunk) cells of the bench frames; the general path --
+// wavefront-uniform mask algebra, list appends -- runs on the rest). Chunks without a single valid pixel behind such a chunk are
+// skipped likewise.
 //  * Invalid pixels are replaced by a value that is far from every valid one AND from the substitutes of the four
 //    neighbours (it alternates with lane and row parity), so "both valid and |a - b| <= maxDiff" is ONE unsigned compare,
 //    t = a + maxDiff - b <= 2 maxDiff, and the all-quiet test is one v_max3 tree over the t's + one compare.
 //  * The pixel left of the chunk comes from the previous chunk's registers (DPP wave_ror / wave_shr), not from carried
 //    scalar state; run ends are detected at the pixel to their right, so a chunk never owes the next one anything.
-// (Column segments -- several wavefronts per band, a run that crosses a segment edge cut in two and re-joined by the seam
-// kernel -- were built and measured in round 6: the band walk of one pair got shorter by what the seam kernel got longer, and
-// every larger launch lost; profiles/r06_speckle.md.)
+// (What was measured on the way and not kept: profiles/r06_speckle.md.)
 struct SpkRun { int parent, size, first, last; };
 // first: bit 31 marks the root of an IN-BAND component (set by the band walk's last phase). size: at such a root the component's
 // size -- in-band pixels first, then what the count kernel adds for roots hooked under it -- or >= kSpkBig once something
@@ -289,9 +287,9 @@ constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x100
 // LOCAL mode: the runs of the walk -- at most kSpkCapR per row and segment -- live in LDS while the band is walked (parent, first,
 // last per run; id = wavefront * N + row * kSpkCapR + k), contacts inside the band are listed there and unioned 64 at a time
 // (LDS atomics: ~100 ns a round trip instead of an L2's), and every record is written to memory ONCE, complete, when the band is
-// done: parent = in-band root, in-band size, first (+ root flag), last. GLOBAL mode (first version of round 6, still the path of
-// a band with more than kSpkCapR runs in some row of some segment): records created and closed in memory during the walk,
-// contacts unioned by L2 atomics, two more sweeps of dependent L2 round trips for sizes and flags.
+// done: parent = in-band root, in-band size, first (+ root flag), last. GLOBAL mode (the path of a band with more than kSpkCapR
+// runs in some row of some segment; 18 us slower per band wavefront where it was the only mode): records created and closed in
+// memory during the walk, contacts unioned by L2 atomics, two more sweeps of dependent L2 round trips for sizes and flags.
 #ifndef SPK_CAPR4
 #define SPK_CAPR4 128
 #endif
