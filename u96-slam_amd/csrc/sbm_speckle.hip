@@ -290,20 +290,12 @@ constexpr int kSpkFar = 0x20000000, kSpkFarStep = 0x01000000, kSpkFarMin = 0x100
 // done: parent = in-band root, in-band size, first (+ root flag), last. GLOBAL mode (the path of a band with more than kSpkCapR
 // runs in some row of some segment; 18 us slower per band wavefront where it was the only mode): records created and closed in
 // memory during the walk, contacts unioned by L2 atomics, two more sweeps of dependent L2 round trips for sizes and flags.
-#ifndef SPK_CAPR4
-#define SPK_CAPR4 128
-#endif
-#ifndef SPK_CAPR2
-#define SPK_CAPR2 256
-#endif
+// (table sizes of 64 / 96 runs per row and workgroups of 1 / 2 wavefronts at one segment per band were measured: re-walks of the
+// busiest bands, and bands that no longer share their look-ahead rows in the CU's cache -- profiles/r06_speckle.md)
 template <int G>
-constexpr int kSpkCapR = G == 2 ? SPK_CAPR2 : SPK_CAPR4;
-#ifndef SPK_NW1
-#define SPK_NW1 4
-#endif
-template <int S>
-constexpr int kSpkWaves = S == 1 ? SPK_NW1 : 4;   // wavefronts per workgroup of the band walk
-template <int G, int NW = 4>
+constexpr int kSpkCapR = G == 2 ? 256 : 128;
+constexpr int kSpkWaves = 4;   // wavefronts per workgroup of the band walk: 4 / S bands x S column segments
+template <int G, int NW = kSpkWaves>
 struct SpkWgLds {
   static constexpr int N = G * kSpkCapR<G>;   // run ids of one wavefront
   int par[NW * N];
@@ -348,7 +340,7 @@ struct SpkLayout {
 // then: the band is walked again in GLOBAL mode). nh[r]: runs of row r in this segment; nsm: seam contacts listed.
 template <int G, int S, bool LOCAL>
 __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d, SpkRun* __restrict__ R, unsigned* __restrict__ sl,
-                                                  const SpkLayout<S> lay, int W, int H, int newval, int maxdiff, SpkWgLds<G, kSpkWaves<S>>& lds,
+                                                  const SpkLayout<S> lay, int W, int H, int newval, int maxdiff, SpkWgLds<G>& lds,
                                                   const int wave, const int band, const int seg, const int cs, const int ce,
                                                   int (&nh)[G + 1], int& nsm) {
   constexpr int CAPR = kSpkCapR<G>;
@@ -561,14 +553,14 @@ __device__ __forceinline__ bool speckle_band_walk(const int16_t* __restrict__ d,
 
 // grid: (ceil(nbands * S / NW), n), block = NW wavefronts = NW / S bands x S column segments
 template <int G, int S>
-__global__ void __launch_bounds__(64 * kSpkWaves<S>) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
+__global__ void __launch_bounds__(64 * kSpkWaves) speckle_band_kernel(const int16_t* __restrict__ disp, SpkRun* __restrict__ runs,
                                                             int* __restrict__ nheads, unsigned* __restrict__ seam,
                                                             int* __restrict__ nseam, const SpkLayout<S> lay, int W, int H, int newval,
                                                             int maxdiff) {
   constexpr int CAPR = kSpkCapR<G>;
   constexpr int N = SpkWgLds<G>::N;
-  constexpr int NW = kSpkWaves<S>;
-  __shared__ SpkWgLds<G, NW> lds;
+  constexpr int NW = kSpkWaves;
+  __shared__ SpkWgLds<G> lds;
   const int lane = threadIdx.x & 63;
   const int SW = lay.SW;
   // S = 1: the four wavefronts are four bands that have nothing to do with each other -- no workgroup barriers
@@ -954,7 +946,7 @@ hipError_t launch_speckle(int16_t* disp, void* runs, int32_t* nheads, uint32_t* 
     auto launch = [&](auto seg) {
       constexpr int SS = decltype(seg)::value;
       const SpkLayout<SS> lay{SW};
-      const dim3 wgrid((nbands * SS + kSpkWaves<SS> - 1) / kSpkWaves<SS>, g.n), wblock(64 * kSpkWaves<SS>);
+      const dim3 wgrid((nbands * SS + kSpkWaves - 1) / kSpkWaves, g.n), wblock(64 * kSpkWaves);
       if (G == 4) hipLaunchKernelGGL((speckle_band_kernel<4, SS>), wgrid, wblock, 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
       else hipLaunchKernelGGL((speckle_band_kernel<2, SS>), wgrid, wblock, 0, s, disp, R, nheads, seam, nseam, lay, g.W, g.H, newval, max_diff);
       hipLaunchKernelGGL(speckle_seam_kernel<SS>, bgrid, dim3(256), 0, s, R, seam, nseam, lay, g.H, G, max_size);
